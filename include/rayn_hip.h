@@ -1,0 +1,212 @@
+/* rayn_hip.h — C ABI of the MI355X-native replacement for rayn's per-sample integrator hot path.
+ *
+ * The reference (fu5ha/rayn, a single Rust binary crate) has no FFI: the replaceable seam is
+ *   Film::render_frame_into(&mut self, world:&World, camera:CameraHandle, integrator:&I, filter:&F,
+ *                           tile_size:Extent2u, frame:usize, time_range:Range<f32>, samples:usize)
+ *   (src/film.rs:382-395), i.e. everything between building the tile list (src/film.rs:397-427) and
+ *   tile_finished (src/film.rs:660-691), together with the trait surface that closure drives:
+ *   Hitable (src/hitable.rs:8-18), Material/BSDF (src/material.rs:11-38), Light (src/light.rs:5-17),
+ *   Camera (src/camera.rs:5-19), Integrator (src/integrator.rs:13-30), Filter (src/filter.rs:7-10).
+ * Trait objects cannot cross to a GPU, so the ABI takes the same surface as a CLOSED SET of POD
+ * descriptors (every concrete type the reference ships) in scene order — order is semantic
+ * (HitableStore::add_hits folds in order, src/hitable.rs:170-210; HitStore::process_hits emits
+ * packets object-major, src/hitable.rs:94-134).
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions return 0 on success or a
+ * negative rayn_status; rayn_hip_last_error() gives the text.  Where the reference panics
+ * (src/film.rs:127,160,197,667; src/material.rs:431) this ABI returns an error code instead.
+ */
+#ifndef RAYN_HIP_H
+#define RAYN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAYN_MAX_HITABLES 16
+#define RAYN_MAX_MATERIALS 16
+#define RAYN_MAX_LIGHTS 16
+#define RAYN_FIS_TABLE_SIZE 512 /* FILTER_TABLE_SIZE, src/filter.rs:187 */
+#define RAYN_FILM_FLOATS_PER_PIXEL 10 /* Color 3 + Alpha 1 + Background 3 + WorldNormal 3 (src/film.rs:103-120) */
+
+typedef enum {
+    RAYN_OK = 0,
+    RAYN_ERR_INVALID_ARG = -1,
+    RAYN_ERR_NO_DEVICE = -2,
+    RAYN_ERR_HIP = -3,
+    RAYN_ERR_NO_WORLD = -4,
+    RAYN_ERR_OOM = -5
+} rayn_status;
+
+typedef struct { float x, y, z; } rayn_vec3;
+
+/* ---- Hitable (src/hitable.rs:8-18) -------------------------------------------------------- */
+typedef enum {
+    RAYN_HITABLE_SPHERE = 0,    /* Sphere<TR>, src/sphere.rs:7-87 (TR = constant Vec3) */
+    RAYN_HITABLE_TRACED_SDF = 1 /* TracedSDF<S>, src/sdf.rs:12-102 */
+} rayn_hitable_kind;
+
+typedef enum {
+    RAYN_SDF_SPHERE = 0,   /* sdfu::Sphere: |p| - r (used by BASELINE config 1) */
+    RAYN_SDF_MANDELBOX = 1 /* MandelBox, src/sdf.rs:104-188 */
+} rayn_sdf_kind;
+
+typedef struct {
+    uint32_t kind;     /* rayn_hitable_kind */
+    uint32_t material; /* MaterialHandle(usize), src/material.rs:55-56 */
+    /* RAYN_HITABLE_SPHERE: Sphere::new(transform_seq, radius, material), src/sphere.rs:14-20 */
+    rayn_vec3 center;
+    float radius;
+    /* RAYN_HITABLE_TRACED_SDF: TracedSDF::new(sdf, material), src/sdf.rs:17-21 */
+    uint32_t sdf_kind;   /* rayn_sdf_kind */
+    uint32_t iterations; /* MandelBox::new(iterations, ..), src/sdf.rs:114 */
+    float box_side;      /* BoxFold::new(side_length), src/sdf.rs:151 */
+    float min_radius;    /* SphereFold::new(min_radius, fixed_radius), src/sdf.rs:172 */
+    float fixed_radius;
+    float scale;         /* MandelBox scale, src/sdf.rs:114 */
+    float sdf_radius;    /* RAYN_SDF_SPHERE radius */
+    uint32_t _pad;
+} rayn_hitable;
+
+/* ---- Material / BSDF (src/material.rs:11-38) ---------------------------------------------- */
+typedef enum {
+    RAYN_MAT_LAMBERTIAN = 0, /* src/material.rs:85-142 */
+    RAYN_MAT_DIELECTRIC = 1, /* src/material.rs:144-257; 'exponent' is the REMAPPED roughness */
+    RAYN_MAT_SKY = 2,        /* src/material.rs:394-449 */
+    RAYN_MAT_EMISSIVE = 3    /* src/material.rs:451-520 (inner Lambertian 0.5 is never sampled) */
+} rayn_material_kind;
+
+typedef struct {
+    uint32_t kind;  /* rayn_material_kind */
+    rayn_vec3 a;    /* albedo | albedo | sky top | emission */
+    rayn_vec3 b;    /* -      | -      | sky bottom | - */
+    float exponent; /* Dielectric: 1 + (1-roughness)^4 * 300, Dielectric::new_remap src/material.rs:167-174 */
+} rayn_material;
+
+/* ---- Light (src/light.rs:5-17): SphereLight::new(pos, rad, emission), src/light.rs:26-34 -- */
+typedef struct {
+    rayn_vec3 pos;
+    float rad;
+    rayn_vec3 emission;
+    uint32_t _pad;
+} rayn_light;
+
+/* ---- Camera (src/camera.rs:5-19) ---------------------------------------------------------- */
+typedef enum {
+    RAYN_CAM_PINHOLE = 0,  /* src/camera.rs:41-119 */
+    RAYN_CAM_THIN_LENS = 1, /* src/camera.rs:120-213 */
+    RAYN_CAM_ORTHOGRAPHIC = 2 /* src/camera.rs:215-285 */
+} rayn_camera_kind;
+
+typedef struct {
+    uint32_t kind;      /* rayn_camera_kind */
+    float res_w, res_h; /* 'resolution: Vec2' argument of ::new */
+    float vfov_or_size; /* vfov in degrees (pinhole, thin lens) | vertical_size (orthographic) */
+    rayn_vec3 origin, at, up;
+    float aperture;     /* thin lens */
+    rayn_vec3 focus;    /* thin lens */
+} rayn_camera;
+
+/* ---- World (src/world.rs:7-13) + VolumeParams (src/volume.rs:1-5) ------------------------- */
+typedef struct {
+    uint32_t n_hitables, n_materials, n_lights;
+    rayn_hitable hitables[RAYN_MAX_HITABLES];    /* HitableStore, scene order */
+    rayn_material materials[RAYN_MAX_MATERIALS]; /* MaterialStore */
+    rayn_light lights[RAYN_MAX_LIGHTS];          /* Vec<Box<dyn Light>> */
+    rayn_camera camera;                          /* the CameraHandle passed to render_frame_into */
+    uint32_t has_scattering; /* coeff_scattering: Option<f32> */
+    float coeff_scattering;
+    uint32_t has_extinction; /* coeff_extinction: Option<f32> */
+    float coeff_extinction;
+} rayn_world_desc;
+
+/* ---- arguments of Film::render_frame_into + the constants it reads ------------------------ */
+typedef struct {
+    uint32_t width, height;   /* Film.res, src/film.rs:180 */
+    uint32_t samples;         /* 'samples' (spp = 4*samples), src/film.rs:391,434,439 */
+    uint32_t tile_w, tile_h;  /* tile_size, src/main.rs:69 */
+    uint32_t max_bounces;     /* PathTracingIntegrator.max_bounces, src/integrator.rs:34 */
+    uint32_t volume_marches;  /* VOLUME_MARCHES_PER_SAMPLE (>= 2: samples_1d[3],[4] are indexed), src/setup.rs:25 */
+    uint32_t frame;           /* seeds the sample tables, src/film.rs:434 */
+    float time_start, time_end; /* time_range, src/main.rs:61-62 */
+    uint32_t max_marches;     /* MAX_MARCHES = 256, src/sdf.rs:9 */
+    uint32_t max_vis_marches; /* MAX_VIS_MARCHES = 100, src/sdf.rs:10 */
+    float sdf_detail_scale;   /* SDF_DETAIL_SCALE, src/setup.rs:37 */
+    float world_radius;       /* WORLD_RADIUS, src/setup.rs:33 */
+    /* multi-GPU film partition (no reference counterpart; tiles are independent, src/film.rs:439-627):
+     * this call renders tiles k with k % tile_step == tile_first, k in the reference's tile order. */
+    uint32_t tile_first, tile_step;
+} rayn_frame_params;
+
+/* counters + timings of the last render (device work only) */
+typedef struct {
+    uint64_t paths;          /* camera paths started */
+    uint64_t segments;       /* valid rays extended (one per path per depth reached) */
+    uint64_t shaded_slots;   /* packet lanes shaded incl. padding lanes */
+    uint64_t tiles;
+    uint64_t batches;
+    double ms_total;         /* HIP-event time of the whole render on the ctx stream */
+    double ms_raygen, ms_extend, ms_bin, ms_shade, ms_compact, ms_resolve;
+    uint64_t launches_extend, launches_shade;
+    uint64_t queue_bytes;    /* algorithmic HBM bytes moved by the queue kernels */
+} rayn_stats;
+
+typedef struct rayn_ctx rayn_ctx;
+
+/* Film::new (src/film.rs:184-203) + device selection.  One ctx per process/GPU. */
+int rayn_hip_create(int device, rayn_ctx** out);
+void rayn_hip_destroy(rayn_ctx* ctx);
+const char* rayn_hip_last_error(const rayn_ctx* ctx);
+
+/* setup::setup() result (src/setup.rs:46-170) flattened; replaces passing &World. */
+int rayn_hip_upload_world(rayn_ctx* ctx, const rayn_world_desc* world);
+
+/* Film::render_frame_into (src/film.rs:382-628) incl. tile_finished's normalisation
+ * (src/film.rs:82-98,660-691).  HOST pointers.  Tables are the ones Samples::new_rd
+ * (src/sampler.rs:18-37), the per-pixel SmallRng scramble (src/film.rs:460-461) and
+ * FilterImportanceSampler::new (src/filter.rs:187-220) produce:
+ *   samples_1d: spp*sets_1d floats, samples_2d: 2*spp*sets_2d floats, scramble: width*height,
+ *   fis_table: 512.  Outputs are full-resolution, bottom-up rows like the reference's film
+ *   (the flip happens only in save_to, src/film.rs:236): color/background/normal 3 floats per
+ *   pixel interleaved, alpha 1.  Pixels of tiles this call does not own are left untouched. */
+int rayn_hip_render_frame(rayn_ctx* ctx, const rayn_frame_params* p,
+                          const float* samples_1d, const float* samples_2d,
+                          const float* scramble, const float* fis_table,
+                          float* out_color, float* out_alpha, float* out_background,
+                          float* out_normal);
+
+/* Same, but every pointer is a DEVICE pointer on the ctx's GPU and the work is enqueued on
+ * 'hip_stream' (a hipStream_t; NULL = the ctx's own stream).  Returns after the last kernel has
+ * been enqueued and the per-depth queue counts have been consumed (the call synchronises the
+ * stream internally once per depth).  This is the entry the bench and the RCCL path use. */
+int rayn_hip_render_frame_device(rayn_ctx* ctx, const rayn_frame_params* p,
+                                 const float* d_samples_1d, const float* d_samples_2d,
+                                 const float* d_scramble, const float* d_fis_table,
+                                 float* d_out_color, float* d_out_alpha, float* d_out_background,
+                                 float* d_out_normal, void* hip_stream);
+
+int rayn_hip_get_stats(const rayn_ctx* ctx, rayn_stats* out);
+
+/* ---- host-side table builders (the a1/a3/a4 rows of SURVEY.md section 8) ------------------ */
+/* 1 + requested_1d_sample_sets(), 2 + requested_2d_sample_sets() (src/film.rs:431-432,
+ * src/integrator.rs:39-45). */
+uint32_t rayn_sets_1d(uint32_t max_bounces, uint32_t volume_marches);
+uint32_t rayn_sets_2d(uint32_t max_bounces, uint32_t volume_marches);
+/* Samples::new_rd(spp, sets_1d, sets_2d, frame), src/sampler.rs:18-37. */
+int rayn_build_rd_tables(uint32_t spp, uint32_t sets_1d, uint32_t sets_2d, uint64_t frame,
+                         float* samples_1d, float* samples_2d);
+/* SmallRng::seed_from_u64(x + y*width).gen::<f32>() for every pixel, src/film.rs:460-461. */
+int rayn_build_scramble(uint32_t width, uint32_t height, float* scramble);
+/* FilterImportanceSampler::new(&BlackmanHarrisFilter::new(radius)), src/filter.rs:12-49,187-220.
+ * filter_kind: 0 BlackmanHarris, 1 Box. */
+int rayn_build_fis_table(uint32_t filter_kind, float radius, float* table512);
+/* number of tiles render_frame_into builds, incl. its under-coverage quirk (src/film.rs:399-404). */
+uint32_t rayn_tile_count(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYN_HIP_H */

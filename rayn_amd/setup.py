@@ -1,0 +1,78 @@
+"""Scene definitions: the reference's `setup::setup()` (src/setup.rs:46-170) and the BASELINE
+config scenes derived from it (S0, S1, S2).  Constants mirror
+src/setup.rs:16-44 and src/main.rs:47-56,69."""
+import numpy as np
+
+from .scene import (BoxFold, CameraStore, Dielectric, Emissive, HitableStore, MandelBox, MaterialStore,
+                    PinholeCamera, Sky, Sphere, SphereFold, SphereLight, SphereSDF, Srgb, TracedSDF,
+                    VolumeParams, World, vec3, _mul)
+
+WORLD_RADIUS = 100.0          # src/setup.rs:33
+SDF_DETAIL_SCALE = 0.5        # src/setup.rs:37
+FRACTAL_ITERATIONS = 12       # src/setup.rs:44
+VOLUME_MARCHES_PER_SAMPLE = 2  # src/setup.rs:25
+MAX_MARCHES = 256             # src/sdf.rs:9
+MAX_VIS_MARCHES = 100         # src/sdf.rs:10
+FRAME_RATE = 24               # src/main.rs:47
+TILE_SIZE = (16, 16)          # src/main.rs:69
+FILTER_RADIUS = 1.5           # src/main.rs:51
+
+
+def _lights_and_proxies(materials, hitables, lights, with_center_light):
+    green = Srgb(1.5, 4.5, 3.0).normalized()
+    blue = Srgb(1.5, 3.0, 4.5).normalized()
+    blue_emissive = materials.add_material(Emissive.new_splat(blue * 3.0))
+    green_emissive = materials.add_material(Emissive.new_splat(green * 3.0))
+    light_pairs = [(vec3(1.2, -1.2, 1.2), 0.15), (vec3(-1.2, 1.2, 1.2), 0.15)]
+    for pos, rad in light_pairs:
+        green_pos = pos.copy()
+        green_pos[1] *= -1.0
+        lights.append(SphereLight(green_pos, rad, green * 40.0))
+        lights.append(SphereLight(pos, rad, blue * 40.0))
+        hitables.push(Sphere(green_pos, float(np.float32(rad) - np.float32(0.01)), green_emissive))
+        hitables.push(Sphere(pos, float(np.float32(rad) - np.float32(0.01)), blue_emissive))
+    if with_center_light:
+        lights.append(SphereLight(vec3(0.0, 0.0, 0.0), 0.25, green * 20.0))
+        hitables.push(Sphere(vec3(0.0, 0.0, 0.0), 0.24, green_emissive))
+
+
+def _camera(resolution):
+    cameras = CameraStore()
+    cam = PinholeCamera((float(resolution[0]), float(resolution[1])), 60.0,
+                        _mul(vec3(-0.45, 0.2, 2.0), 2.25), vec3(0.0, 0.0, 0.0), vec3(0.0, 1.0, 0.0))
+    return cameras, cameras.add_camera(cam)
+
+
+def setup(resolution=(1280, 720), volumes=True, sdf="mandelbox"):
+    """`setup::setup()` (src/setup.rs:46-170).  volumes=True is the shipped scene (S2: rho_s 0.25,
+    rho_t 0.035); volumes=False is S1 (both None).  sdf="sphere" swaps the fractal for a unit
+    sphere SDF and drops the central light (S0, BASELINE config 1)."""
+    materials, hitables, lights = MaterialStore(), HitableStore(), []
+    volume_params = VolumeParams(0.25, 0.035) if volumes else VolumeParams(None, None)
+    sky = materials.add_material(Sky(Srgb(0.3, 0.4, 0.6), Srgb(0.2, 0.3, 0.6) * 0.05))
+    hitables.push(Sphere(vec3(0.0, 0.0, 0.0), WORLD_RADIUS, sky))
+    grey = materials.add_material(Dielectric.new_remap(Srgb(0.2, 0.2, 0.2), 0.6))
+    if sdf == "mandelbox":
+        hitables.push(TracedSDF(MandelBox(FRACTAL_ITERATIONS, BoxFold(1.0), SphereFold(0.01, 1.9), -2.1), grey))
+    elif sdf == "sphere":
+        hitables.push(TracedSDF(SphereSDF(1.0), grey))
+    else:
+        raise ValueError(sdf)
+    _lights_and_proxies(materials, hitables, lights, with_center_light=(sdf == "mandelbox"))
+    cameras, camera = _camera(resolution)
+    return camera, World(hitables, lights, materials, cameras, volume_params)
+
+
+def setup_s0(resolution=(256, 256)):
+    """BASELINE config 1: single-sphere SDF scene, volumes off."""
+    return setup(resolution, volumes=False, sdf="sphere")
+
+
+def setup_s1(resolution=(1920, 1080)):
+    """BASELINE configs 2/4: shipped MandelBox scene, volumes off."""
+    return setup(resolution, volumes=False, sdf="mandelbox")
+
+
+def setup_s2(resolution=(1920, 1080)):
+    """BASELINE config 3: shipped MandelBox scene with the homogeneous volume."""
+    return setup(resolution, volumes=True, sdf="mandelbox")
