@@ -206,6 +206,34 @@ int rayn_build_fis_table(uint32_t filter_kind, float radius, float* table512);
 /* number of tiles render_frame_into builds, incl. its under-coverage quirk (src/film.rs:399-404). */
 uint32_t rayn_tile_count(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h);
 
+/* ---- diagnostics (no reference counterpart) ------------------------------------------------ */
+/* timing: bracket every kernel launch with HIP events and fill rayn_stats.ms_*; count_evals: run
+ * the instrumented kernel variants that count SDF distance evaluations (roofline accounting). */
+int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals);
+int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t* extend_evals, uint64_t* shade_evals);
+/* path-pool capacity per batch of tiles (default 2^25 paths ~ 3.3 GB of HBM). */
+int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
+/* 0: a*b+c unfused (reference default build), 1: fused (see include/rayn_detmath.h). */
+int rayn_hip_fma_policy(void);
+/* sizeof() of the ABI structs as compiled: 0 world_desc, 1 frame_params, 2 stats, 3 hitable,
+ * 4 material, 5 light, 6 camera — lets a binding verify its layout. */
+size_t rayn_hip_sizeof(int which);
+
+/* ---- test probes: device per-lane primitives on caller data (HOST pointers).  They exist so the
+ * parity tests can compare single functions with the CPU oracle lane for lane:
+ *   SDF::dist (src/sdf.rs:125-140), HitableStore::add_hits' closest hit (src/hitable.rs:177-198;
+ *   out_obj 0xFFFFFFFF = none), HitableStore::test_occluded (src/hitable.rs:164-168), and the pinned
+ *   elementary functions (op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b)). */
+int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t hitable_index,
+                            const float* pts_xyz, float* out, uint32_t n);
+int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth,
+                               const float* org_xyz, const float* dir_xyz, float* out_t,
+                               uint32_t* out_obj, uint32_t n);
+int rayn_hip_probe_occluded(rayn_ctx* ctx, const rayn_frame_params* p, const float* start_xyz,
+                            const float* end_xyz, float* out, uint32_t n);
+int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const float* b, float* out,
+                           uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,72 @@
+"""Loader of the in-tree HIP library (rayn_amd/csrc/librayn_hip.so) — the ONLY compute backend.
+There is no CPU fallback: if the library is missing or no GPU is present, calls fail loudly."""
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "librayn_hip.so")
+
+# every symbol include/rayn_hip.h declares
+EXPORTS = [
+    "rayn_hip_create", "rayn_hip_destroy", "rayn_hip_last_error", "rayn_hip_upload_world", "rayn_hip_render_frame",
+    "rayn_hip_render_frame_device", "rayn_hip_get_stats", "rayn_sets_1d", "rayn_sets_2d", "rayn_build_rd_tables",
+    "rayn_build_scramble", "rayn_build_fis_table", "rayn_tile_count", "rayn_hip_set_profiling", "rayn_hip_get_eval_counts",
+    "rayn_hip_set_batch_paths", "rayn_hip_fma_policy", "rayn_hip_sizeof", "rayn_hip_probe_sdf_dist",
+    "rayn_hip_probe_closest_hit", "rayn_hip_probe_occluded", "rayn_hip_probe_detmath",
+]
+
+
+class RaynHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP extension for gfx950 with hipcc (rayn_amd/csrc/Makefile)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _CSRC], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RaynHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+        L.rayn_hip_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rayn_hip_destroy.argtypes = [vp]
+        L.rayn_hip_destroy.restype = None
+        L.rayn_hip_last_error.argtypes = [vp]
+        L.rayn_hip_last_error.restype = C.c_char_p
+        L.rayn_hip_upload_world.argtypes = [vp, C.POINTER(_abi.WorldDesc)]
+        L.rayn_hip_render_frame.argtypes = [vp, C.POINTER(_abi.FrameParams), fp, fp, fp, fp, fp, fp, fp, fp]
+        L.rayn_hip_render_frame_device.argtypes = [vp, C.POINTER(_abi.FrameParams)] + [vp] * 9
+        L.rayn_hip_get_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
+        L.rayn_sets_1d.restype = C.c_uint32
+        L.rayn_sets_1d.argtypes = [C.c_uint32, C.c_uint32]
+        L.rayn_sets_2d.restype = C.c_uint32
+        L.rayn_sets_2d.argtypes = [C.c_uint32, C.c_uint32]
+        L.rayn_build_rd_tables.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp, fp]
+        L.rayn_build_scramble.argtypes = [C.c_uint32, C.c_uint32, fp]
+        L.rayn_build_fis_table.argtypes = [C.c_uint32, C.c_float, fp]
+        L.rayn_tile_count.restype = C.c_uint32
+        L.rayn_tile_count.argtypes = [C.c_uint32] * 4
+        L.rayn_hip_set_profiling.argtypes = [vp, C.c_int, C.c_int]
+        L.rayn_hip_get_eval_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.rayn_hip_set_batch_paths.argtypes = [vp, C.c_uint64]
+        L.rayn_hip_sizeof.restype = C.c_size_t
+        L.rayn_hip_sizeof.argtypes = [C.c_int]
+        L.rayn_hip_probe_sdf_dist.argtypes = [vp, C.POINTER(_abi.FrameParams), C.c_uint32, fp, fp, C.c_uint32]
+        L.rayn_hip_probe_closest_hit.argtypes = [vp, C.POINTER(_abi.FrameParams), C.c_uint32, fp, fp, fp, up, C.c_uint32]
+        L.rayn_hip_probe_occluded.argtypes = [vp, C.POINTER(_abi.FrameParams), fp, fp, fp, C.c_uint32]
+        L.rayn_hip_probe_detmath.argtypes = [vp, C.c_uint32, fp, fp, fp, C.c_uint32]
+        _lib = L
+    return _lib

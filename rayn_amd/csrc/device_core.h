@@ -1,0 +1,402 @@
+// device_core.h — per-lane (scalar) device restatement of rayn's arithmetic for the wavefront
+// kernels.  One GPU lane = one lane of a reference f32x4 packet; cross-lane effects of the packet
+// code (the 4 light picks of a packet, src/integrator.rs:76-93,100-131) are handled in the shade
+// kernel with wave shuffles.  Operation order follows the reference line by line so results are
+// bit-identical with the CPU oracle; transcendentals and the mul_add policy come from
+// include/rayn_detmath.h.  Compile with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/rayn_detmath.h"
+#include "device_scene.h"
+#include "kernels.h"
+
+namespace rayn {
+
+#define RD __device__ __forceinline__
+
+// ---- f32 helpers with wide/SSE semantics -------------------------------------------------------
+RD float fmaxs(float a, float b) { return a > b ? a : b; } // a.max(b): maxps
+RD float fmins(float a, float b) { return a < b ? a : b; } // a.min(b): minps
+RD float signum(float x) { return x != x ? x : __builtin_copysignf(1.0f, x); }
+RD float muladd(float a, float b, float c) { return rayn_muladd(a, b, c); }
+RD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; } // sdfu Lerp
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float TWO_PI_F = 6.28318530717958647692f;
+constexpr float FRAC_PI_2_F = 1.57079632679489661923f;
+constexpr float FRAC_PI_4_F = 0.78539816339744830962f;
+constexpr float EPSILON_F = 1.1920929e-7f;
+
+// ---- Vec3 (ultraviolet 0.4.6 operation order) --------------------------------------------------
+RD f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+RD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RD f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RD f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+RD f3 operator*(float s, f3 a) { return f3{s * a.x, s * a.y, s * a.z}; }
+RD f3 operator/(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
+RD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+RD float dot(f3 a, f3 b) { return muladd(a.x, b.x, muladd(a.y, b.y, a.z * b.z)); }
+RD float mag_sq(f3 a) { return dot(a, a); }
+RD float mag(f3 a) { return __builtin_sqrtf(mag_sq(a)); }
+RD f3 normalized(f3 a) { float r = 1.0f / mag(a); return f3{a.x * r, a.y * r, a.z * r}; }
+RD f3 cross(f3 a, f3 b) {
+    return f3{muladd(a.y, b.z, -a.z * b.y), muladd(a.z, b.x, -a.x * b.z), muladd(a.x, b.y, -a.y * b.x)};
+}
+RD f3 muladd3(f3 a, float m, f3 c) { return f3{muladd(a.x, m, c.x), muladd(a.y, m, c.y), muladd(a.z, m, c.z)}; }
+RD f3 reflected(f3 v, f3 n) { return v - (2.0f * dot(v, n)) * n; }
+RD float component_max(f3 a) { return fmaxs(fmaxs(a.x, a.y), a.z); }
+RD bool any_nan(f3 a) { return a.x != a.x || a.y != a.y || a.z != a.z; }
+
+struct Basis { f3 c0, c1, c2; };
+RD f3 mul(const Basis& m, f3 v) { return m.c0 * v.x + m.c1 * v.y + m.c2 * v.z; }
+// src/math.rs:49-59
+RD Basis orthonormal_basis(f3 nor) {
+    float ks = signum(nor.z);
+    float ka = 1.0f / (1.0f + __builtin_fabsf(nor.z));
+    float kb = -ks * nor.x * nor.y * ka;
+    Basis b;
+    b.c0 = f3{1.0f - nor.x * nor.x * ka, ks * kb, -ks * nor.x};
+    b.c1 = f3{kb, ks - nor.y * nor.y * ka * ks, -nor.y};
+    b.c2 = nor;
+    return b;
+}
+
+// ---- sampling maps (src/math.rs) -----------------------------------------------------------------
+RD void concentric_circle_map(float u0, float u1, float* ox, float* oy) { // :201-219
+    float a = muladd(u0, 2.0f, -1.0f);
+    float b = muladd(u1, 2.0f, -1.0f);
+    if (a == 0.0f && b == 0.0f) b = 0.0001f;
+    float phi1 = FRAC_PI_4_F * b / a;
+    float phi2 = muladd(-FRAC_PI_4_F / b, a, FRAC_PI_2_F);
+    bool mask = (a * a) > (b * b);
+    float r = mask ? a : b;
+    float phi = mask ? phi1 : phi2;
+    float s, c;
+    dm_sincosf(phi, &s, &c);
+    *ox = r * c;
+    *oy = r * s;
+}
+RD f3 cosine_weighted_in_hemisphere(float u0, float u1) { // :99-103
+    float x, y;
+    concentric_circle_map(u0, u1, &x, &y);
+    float m2 = muladd(x, x, y * y);
+    float z = __builtin_sqrtf(1.0f - fmins(m2, 1.0f));
+    return f3{x, y, z};
+}
+RD f3 cosine_power_weighted(float u0, float u1, float power) { // :106-113
+    float a = dm_powf(u0, 1.0f / (power + 1.0f));
+    float a2 = a * a;
+    float b = __builtin_sqrtf(1.0f - a2);
+    float s, c;
+    dm_sincosf(2.0f * u1, &s, &c);
+    return f3{b * c, b * s, a};
+}
+RD float f_schlick(float cosv, float f0) { // :122-124
+    float x = 1.0f - cosv;
+    float x2 = x * x;
+    return f0 + (1.0f - f0) * ((x2 * x2) * x);
+}
+
+// ---- Samples (src/sampler.rs:62-64,92-94) ----------------------------------------------------------
+
+RD float sample_1d(const Tables& t, uint32_t n, uint32_t sample, float scramble, uint32_t set) {
+    return dm_fractf(t.s1d[sample + n * set] + scramble);
+}
+RD float sample_2d(const Tables& t, uint32_t n, uint32_t dim, uint32_t sample, float scramble, uint32_t set) {
+    return dm_fractf(t.s2d[dim + sample * 2 + n * 2 * set] + scramble);
+}
+// FilterImportanceSampler::sample, src/filter.rs:222-235
+RD float fis_sample(const float* __restrict__ inverse_cdf, float u) {
+    u = 2.0f * (u - 0.5f);
+    float mult = u < 0.0f ? -1.0f : 1.0f;
+    u = __builtin_fabsf(u);
+    u = fmaxs(u, 0.0f);
+    u = fmins(u, 0.99999f);
+    float idx_full = u * (float)(RAYN_FIS_TABLE_SIZE - 1);
+    uint32_t idx = (uint32_t)__builtin_floorf(idx_full);
+    float t = dm_fractf(idx_full);
+    return mult * lerpf(inverse_cdf[idx], inverse_cdf[idx + 1], t);
+}
+
+// ---- SDFs (src/sdf.rs:104-188; sdfu::Sphere) ---------------------------------------------------------
+template <bool COUNT>
+RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
+    if (COUNT) evals++;
+    if (h.sdf_kind == RAYN_SDF_MANDELBOX) {
+        const f3 offset = p;
+        float dr = 1.0f;
+        const float l = h.box_l, nl = -h.box_l, s = h.scale;
+        for (uint32_t i = 0; i < h.iterations; i++) {
+            // box_fold: clamped(-l, l).mul_add(2, -p)
+            p.x = muladd(fmins(fmaxs(p.x, nl), l), 2.0f, -p.x);
+            p.y = muladd(fmins(fmaxs(p.y, nl), l), 2.0f, -p.y);
+            p.z = muladd(fmins(fmaxs(p.z, nl), l), 2.0f, -p.z);
+            // sphere_fold
+            float r2 = mag_sq(p);
+            float m = fmaxs(1.0f, h.fixed_rad_sq / fmaxs(h.min_rad_sq, r2));
+            p.x *= m; p.y *= m; p.z *= m;
+            dr *= m;
+            p.x = muladd(p.x, s, offset.x);
+            p.y = muladd(p.y, s, offset.y);
+            p.z = muladd(p.z, s, offset.z);
+            dr = muladd(-dr, s, 1.0f);
+        }
+        return mag(p) / __builtin_fabsf(dr);
+    }
+    return mag(p) - h.sdf_radius;
+}
+
+// hit threshold closure, src/film.rs:540-551 (Camera::half_pixel_size_at src/camera.rs:116,210,282)
+struct Thr { float k; bool constant; };
+RD Thr make_thr(const DScene& sc, uint32_t depth) {
+    Thr t;
+    if (depth == 0) { t.k = sc.cam.half_pixel_size; t.constant = sc.cam.kind == RAYN_CAM_ORTHOGRAPHIC; }
+    else { t.k = 0.0001f * 2.0f * (float)depth; t.constant = false; }
+    return t;
+}
+RD float thr_at(const Thr& th, float t) { return th.constant ? th.k : th.k * t; }
+
+// TracedSDF::hit, src/sdf.rs:59-83 (per lane; a stopped lane is idempotent in the packet loop)
+template <bool COUNT>
+RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, const Thr& th, uint32_t& evals) {
+    float t = sdf_dist<COUNT>(h, o, evals);
+    const bool nan = t != t;
+    const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
+    for (uint32_t m = 0; m < sc.max_marches; m++) {
+        f3 p = muladd3(d, t, o);
+        float dist = sdf_dist<COUNT>(h, p, evals);
+        bool hit = __builtin_fabsf(dist) < fmaxs(c0, c1 * thr_at(th, t));
+        bool gt = t > t_max;
+        if (hit || nan || gt) break;
+        t = t + dist;
+    }
+    return t;
+}
+// TracedSDF::occluded, src/sdf.rs:25-57 (returns 1 = visible, 0 = occluded)
+template <bool COUNT>
+RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, uint32_t& evals) {
+    f3 dir = end - start;
+    float max_dist = mag(dir);
+    dir = dir / max_dist;
+    float dist0 = sdf_dist<COUNT>(h, start, evals);
+    const bool nan = dist0 != dist0;
+    if (sc.max_vis_marches == 0) return ((dist0 < 0.0001f) && !((dist0 > max_dist) || nan)) ? 0.0f : 1.0f;
+    const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
+    float t = dist0;
+    for (uint32_t m = 0; m < sc.max_vis_marches; m++) {
+        if ((t > max_dist) || nan) return 1.0f;
+        f3 p = muladd3(dir, t, start);
+        float dist = sdf_dist<COUNT>(h, p, evals);
+        if (__builtin_fabsf(dist) < fmaxs(c0, c1 * t)) return 0.0f;
+        t = t + dist;
+    }
+    return 1.0f;
+}
+// sdfu normals_fast (tetrahedron), called at src/sdf.rs:94-96
+template <bool COUNT>
+RD f3 sdf_normal(const DHitable& h, f3 p, float eps, uint32_t& evals) {
+    float d1 = sdf_dist<COUNT>(h, f3{p.x + eps, p.y + -eps, p.z + -eps}, evals);
+    float d2 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + -eps, p.z + eps}, evals);
+    float d3 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + eps, p.z + -eps}, evals);
+    float d4 = sdf_dist<COUNT>(h, f3{p.x + eps, p.y + eps, p.z + eps}, evals);
+    f3 g = f3{1.0f * d1, -1.0f * d1, -1.0f * d1} + f3{-1.0f * d2, -1.0f * d2, 1.0f * d2} +
+           f3{-1.0f * d3, 1.0f * d3, -1.0f * d3} + f3{1.0f * d4, 1.0f * d4, 1.0f * d4};
+    return normalized(g);
+}
+
+// ---- Sphere (src/sphere.rs:23-71) ------------------------------------------------------------------
+RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max) {
+    f3 oc = o - h.center;
+    float b = dot(oc, d);
+    float c = mag_sq(oc) - h.radius_sq;
+    float descrim = b * b - c;
+    bool desc_pos = descrim > 0.0f;
+    float desc_sqrt = __builtin_sqrtf(descrim);
+    float t1 = -b - desc_sqrt;
+    bool t1_valid = (t1 > 0.0001f) && (t1 <= t_max) && desc_pos;
+    float t2 = -b + desc_sqrt;
+    bool t2_valid = (t2 > 0.0001f) && (t2 <= t_max) && desc_pos;
+    bool take_t1 = (t1 < t2) && t1_valid;
+    float t = take_t1 ? t1 : t2;
+    return (t1_valid || t2_valid) ? t : 3.40282347e+38f;
+}
+RD float sphere_occluded(const DHitable& h, f3 start, f3 end) {
+    f3 dir = end - start;
+    float dist = mag(dir);
+    dir = dir / dist;
+    f3 oc = start - h.center;
+    float b = dot(oc, dir);
+    float c = mag_sq(oc) - h.radius_sq;
+    float descrim = b * b - c;
+    bool desc_pos = descrim > 0.0f;
+    float desc_sqrt = __builtin_sqrtf(descrim);
+    float t1 = -b - desc_sqrt;
+    float t2 = -b + desc_sqrt;
+    float mn = fmins(t1, t2);
+    bool valid = (mn > 0.001f) && (t1 <= dist) && desc_pos;
+    return valid ? 0.0f : 1.0f;
+}
+
+// HitableStore::add_hits fold, src/hitable.rs:177-198: closest-so-far is the next t_max.
+template <bool COUNT>
+RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float* out_t, uint32_t* out_obj, uint32_t& evals) {
+    float closest = sc.t_max;
+    uint32_t id = OBJ_NONE;
+    for (uint32_t k = 0; k < sc.n_hitables; k++) {
+        const DHitable& h = sc.h[k];
+        float t = h.kind == RAYN_HITABLE_SPHERE ? sphere_hit(h, o, d, closest) : sdf_hit<COUNT>(sc, h, o, d, closest, th, evals);
+        if (t < closest) { closest = t; id = k; }
+    }
+    *out_t = closest;
+    *out_obj = id;
+}
+// HitableStore::test_occluded, src/hitable.rs:164-168.  Every factor is exactly 0 or 1, so the
+// product is order-independent: analytic spheres first, SDF marches only if still visible.
+template <bool COUNT>
+RD float test_occluded(const DScene& sc, f3 start, f3 end, uint32_t& evals) {
+    for (uint32_t k = 0; k < sc.n_hitables; k++)
+        if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], start, end) == 0.0f) return 0.0f;
+    for (uint32_t k = 0; k < sc.n_hitables; k++)
+        if (sc.h[k].kind != RAYN_HITABLE_SPHERE && sdf_occluded<COUNT>(sc, sc.h[k], start, end, evals) == 0.0f) return 0.0f;
+    return 1.0f;
+}
+
+// ---- SphereLight (src/light.rs:38-107) ---------------------------------------------------------------
+RD void light_sample(const DLight& L, float u0, float u1, f3 p, f3* out_point, float* out_pdf) {
+    f3 dir_to_light = L.pos - p;
+    float dist_sq = mag_sq(dir_to_light);
+    float dist = __builtin_sqrtf(dist_sq);
+    dir_to_light = dir_to_light / dist;
+    Basis basis = orthonormal_basis(-dir_to_light);
+    float r2 = L.rad * L.rad;
+    float sin_theta_max_2 = r2 / dist_sq;
+    float cos_theta_max = __builtin_sqrtf(fmaxs(0.0f, 1.0f - sin_theta_max_2));
+    float cos_theta = (1.0f - u0) + u0 * cos_theta_max;
+    float sin_theta = __builtin_sqrtf(fmaxs(0.0f, 1.0f - cos_theta * cos_theta));
+    float phi = u1 * TWO_PI_F;
+    float ds = dist * cos_theta - __builtin_sqrtf(fmaxs(0.0f, r2 - dist_sq * sin_theta * sin_theta));
+    float cos_alpha = (dist_sq + r2 - ds * ds) / (2.0f * dist * L.rad);
+    float sin_alpha = __builtin_sqrtf(fmaxs(0.0f, 1.0f - cos_alpha * cos_alpha));
+    float sin_phi, cos_phi;
+    dm_sincosf(phi, &sin_phi, &cos_phi);
+    f3 offset = basis.c0 * sin_alpha * cos_phi + basis.c1 * sin_alpha * sin_phi + basis.c2 * cos_alpha;
+    *out_point = L.pos + offset * L.rad;
+    *out_pdf = 1.0f / (TWO_PI_F * (1.0f - cos_theta_max)); // uniform_cone_pdf
+}
+RD void light_sample_volume(const DLight& L, float sample, f3 ray_o, f3 ray_d, float max_distance, float* out_dist, float* out_pdf) {
+    float delta = dot(L.pos - ray_o, ray_d);
+    f3 closest_point = ray_o + delta * ray_d;
+    float d = mag(closest_point - L.pos);
+    float theta_a = dm_atan2f(-delta, d);
+    float theta_b = dm_atan2f(max_distance - delta, d);
+    float t = d * dm_tanf(lerpf(theta_a, theta_b, sample));
+    *out_dist = delta + t;
+    *out_pdf = d / ((theta_b - theta_a) * muladd(d, d, t * t));
+}
+
+// ---- BSDFs (src/material.rs) -----------------------------------------------------------------------------
+// BSDF::f as CALLED: f(wo, wi, n).  DielectricBSDF declares the parameters as (wi, wo, n)
+// (src/material.rs:195), so its 'wi' is the caller's wo — kept literally.
+RD f3 bsdf_f(const DMaterial& m, f3 arg0, f3 arg1, f3 n) {
+    if (m.kind == RAYN_MAT_DIELECTRIC) {
+        float dt = fmaxs(0.0f, dot(arg0, n));
+        float fresnel = f_schlick(dt, 0.04f);
+        f3 half = normalized(arg1 + arg0);
+        float cos_alpha = dm_powf(fmaxs(0.0f, dot(half, n)), m.exponent);
+        float spec_factor = cos_alpha * (m.exponent + 2.0f) / (2.0f * PI_F);
+        f3 spec_f = f3{1.0f, 1.0f, 1.0f} * spec_factor * fresnel;
+        f3 diffuse_f = m.a / PI_F * (1.0f - fresnel);
+        return spec_f + diffuse_f;
+    }
+    if (m.kind == RAYN_MAT_LAMBERTIAN) return m.a / PI_F;
+    return f3{0.0f, 0.0f, 0.0f}; // Emissive (:503-505); Sky::f panics in the reference and is never reached
+}
+RD f3 bsdf_le(const DMaterial& m, f3 wo) {
+    if (m.kind == RAYN_MAT_SKY) { // :444-448
+        float t = 0.5f * (wo.y + 1.0f);
+        return m.a * (1.0f - t) + m.b * t;
+    }
+    if (m.kind == RAYN_MAT_EMISSIVE) return m.a;
+    return f3{0.0f, 0.0f, 0.0f};
+}
+struct Scatter { f3 wi, f; float pdf; };
+RD Scatter bsdf_scatter(const DMaterial& m, f3 wo, f3 normal, const Basis& basis, float s1, float u0, float u1, float u2, float u3) {
+    Scatter se;
+    if (m.kind == RAYN_MAT_DIELECTRIC) { // :207-256
+        float cosv = __builtin_fabsf(dot(normal, wo));
+        f3 diffuse_sample = cosine_weighted_in_hemisphere(u0, u1);
+        f3 diffuse_bounce = normalized(mul(basis, diffuse_sample));
+        float diffuse_pdf = fmaxs(0.00001f, diffuse_sample.z / PI_F);
+        f3 diffuse_f = m.a / PI_F;
+        f3 spec_sample = cosine_power_weighted(u2, u3, m.exponent);
+        f3 reflection = reflected(wo, normal);
+        Basis rb = orthonormal_basis(reflection);
+        f3 spec_bounce = normalized(mul(rb, spec_sample));
+        float cos_alpha_pow = fmaxs(dm_powf(spec_sample.z, m.exponent), EPSILON_F);
+        float spec_pdf = (m.exponent + 1.0f) / TWO_PI_F * cos_alpha_pow;
+        float spec_coeff = (m.exponent + 2.0f) / TWO_PI_F * cos_alpha_pow;
+        if (dot(normal, spec_bounce) < 0.0f) spec_coeff = 0.0f;
+        f3 spec_f = f3{1.0f, 1.0f, 1.0f} * spec_coeff;
+        float fresnel = f_schlick(cosv, 0.04f);
+        bool pick_spec = s1 < fresnel;
+        se.wi = pick_spec ? spec_bounce : diffuse_bounce;
+        se.f = pick_spec ? spec_f : diffuse_f;
+        se.pdf = fresnel * spec_pdf + (1.0f - fresnel) * diffuse_pdf;
+    } else { // Lambertian :118-137
+        f3 diffuse_sample = cosine_weighted_in_hemisphere(u0, u1);
+        se.wi = normalized(mul(basis, diffuse_sample));
+        se.pdf = diffuse_sample.z / PI_F;
+        se.f = m.a / PI_F;
+    }
+    return se;
+}
+
+// ---- cameras (src/camera.rs) ---------------------------------------------------------------------------------
+RD void camera_ray(const DCamera& c, float uvx, float uvy, float lens0, float lens1, f3* out_o, f3* out_d) {
+    f3 o = c.origin, a = c.at, u = c.up;
+    if (c.kind == RAYN_CAM_PINHOLE) { // :81-114
+        f3 basis_w = normalized(o - a);
+        f3 basis_u = normalized(cross(u, basis_w));
+        f3 basis_v = cross(basis_w, basis_u);
+        f3 lower_left = o - basis_u * c.half_w - basis_v * c.half_h - basis_w;
+        f3 horiz = basis_u * c.half_w * 2.0f * uvx;
+        f3 verti = basis_v * c.half_h * 2.0f * uvy;
+        *out_o = o;
+        *out_d = normalized(lower_left + horiz + verti - o);
+    } else if (c.kind == RAYN_CAM_THIN_LENS) { // :168-208
+        float focus_dist = mag(c.focus - o);
+        f3 basis_w = normalized(o - a);
+        f3 basis_u = normalized(cross(u, basis_w));
+        f3 basis_v = cross(basis_w, basis_u);
+        f3 lower_left = o - basis_u * c.half_w * focus_dist - basis_v * c.half_h * focus_dist - basis_w * focus_dist;
+        f3 horiz = basis_u * c.half_w * focus_dist * 2.0f * uvx;
+        f3 verti = basis_v * c.half_h * focus_dist * 2.0f * uvy;
+        float rx, ry;
+        concentric_circle_map(lens0, lens1, &rx, &ry);
+        rx = rx * c.aperture; ry = ry * c.aperture;
+        f3 offset = basis_u * rx + basis_v * ry;
+        f3 o2 = o + offset;
+        *out_o = o2;
+        *out_d = normalized(lower_left + horiz + verti - o2);
+    } else { // orthographic :249-280
+        f3 basis_w = normalized(a - o);
+        f3 basis_u = normalized(cross(basis_w, u));
+        f3 basis_v = cross(basis_u, basis_w);
+        f3 lower_left = o - basis_u * c.half_w - basis_v * c.half_h;
+        f3 offset = basis_u * uvx * c.full_w + basis_v * uvy * c.full_h;
+        *out_o = lower_left + offset;
+        *out_d = basis_w;
+    }
+}
+
+// `(x * n_lights).floor() as usize`, clamped where the reference would index out of bounds.
+RD uint32_t light_index(float s, uint32_t nl) {
+    float f = __builtin_floorf(s * (float)nl);
+    if (!(f > 0.0f)) return 0;
+    uint32_t i = f >= 4.0e9f ? 0xFFFFFFFFu : (uint32_t)f;
+    return i < nl ? i : nl - 1;
+}
+
+} // namespace rayn

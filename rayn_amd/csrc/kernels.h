@@ -1,0 +1,48 @@
+// kernels.h — host-visible launch wrappers of kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_scene.h"
+
+namespace rayn {
+
+constexpr uint32_t SCAN_NC_BIN = 16; // = RAYN_MAX_HITABLES: classes of the bin scan
+
+// SoA path pool (device pointers)
+struct Pool {
+    float *ox, *oy, *oz, *dx, *dy, *dz, *time;
+    float *lr, *lg, *lb, *tr, *tg, *tb;
+    float* hit_t;
+    uint8_t* hit_obj;
+    uint32_t *pix, *samp;
+    uint32_t* term_key; // bit31 Background, bits 26..30 depth, bits 0..25 binned slot; INVALID = dropped
+    float *n0x, *n0y, *n0z;
+    uint8_t* obj0;
+};
+
+struct Tables { const float* __restrict__ s1d; const float* __restrict__ s2d; const float* __restrict__ fis; };
+
+void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
+                   Pool pool, uint32_t* q, uint32_t n_pool);
+void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
+                   uint8_t* ent_obj, uint8_t* grp_cnt, unsigned long long* evals);
+void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
+                      const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
+                      uint32_t* tile_valid);
+void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
+                        uint32_t* ogb, uint32_t* ogc, uint32_t* totals);
+void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
+                        const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq);
+void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
+                  uint32_t n_slots, Pool pool, uint8_t* alive, uint8_t* bgrp_cnt, unsigned long long* evals);
+void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
+                            const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn);
+void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
+                    float* out_color, float* out_alpha, float* out_background, float* out_normal);
+void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n);
+void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n);
+void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n);
+void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const float* b, float* out, uint32_t n);
+
+} // namespace rayn

@@ -1,0 +1,581 @@
+// kernels.hip — wavefront kernels of the rayn hot path for gfx950 (MI355X).
+//
+// Data layout in HBM (per batch of film tiles; DESIGN.md "Data layout"):
+//   path pool   SoA, one slot per camera path, pixel-major / sample-minor inside a tile, tiles
+//               64-aligned:  origin xyz, dir xyz, time, radiance rgb, throughput rgb, hit_t, pixel,
+//               sample, term_key, depth-0 normal + object.  A path never moves; queues hold indices.
+//   ray queue   u32 pool indices, dense per tile in the reference's order, each tile's segment padded
+//               to a multiple of 64 (one wavefront) with INVALID.  'grp' = one 64-slot group.
+//   binned q    the queue after the stable per-tile partition by hit object (object-major, insertion
+//               order, every object bin padded to x4 = the f32x4 packets of HitStore::process_hits,
+//               src/hitable.rs:94-134).  Four consecutive slots are one reference packet.
+// Order is semantic: partition and compaction are STABLE prefix sums built from wave
+// ballots (mbcnt) + a block scan — never atomics-append.
+#include <hip/hip_runtime.h>
+
+#include "device_core.h"
+#include "kernels.h"
+
+namespace rayn {
+
+RD uint32_t lane_id() { return threadIdx.x & 63u; }
+// number of set bits of a 64-bit wave mask below this lane
+RD uint32_t mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8: tile ray-gen loop, src/film.rs:456-529 (+ sample_uv :695-709, Camera::get_rays).
+// One thread per pool slot.  Pool order inside a tile: x outer, y inner, sample innermost.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
+                                                 const DTile* __restrict__ tiles, const uint32_t* __restrict__ pgrp_tile,
+                                                 Pool pool, uint32_t* __restrict__ q, uint32_t n_pool) {
+    const uint32_t P = blockIdx.x * blockDim.x + threadIdx.x;
+    if (P >= n_pool) return;
+    const DScene& sc = *scp;
+    const DTile tile = tiles[pgrp_tile[P >> 6]];
+    const uint32_t p = P - tile.pool_base;
+    pool.term_key[P] = INVALID;
+    pool.obj0[P] = (uint8_t)OBJ_NONE;
+    if (p >= tile.n_paths) { q[P] = INVALID; return; }
+    const uint32_t spp = sc.spp;
+    const uint32_t s = p % spp, lpix = p / spp;
+    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
+    const uint32_t x = tile.x0 + lx, y = tile.y0 + ly;
+    const uint32_t pix = x + y * sc.width;
+    const float scr = scramble[pix];
+    // sample_uv
+    float u0 = sample_2d(tab, spp, 0, s, scr, 0), u1 = sample_2d(tab, spp, 1, s, scr, 0);
+    float fx = fis_sample(tab.fis, u0), fy = fis_sample(tab.fis, u1);
+    float scx = ((float)x + 0.5f) + fx, scy = ((float)y + 0.5f) + fy;
+    float uvx = sc.ndc_x * scx, uvy = sc.ndc_y * scy;
+    float time = sc.time_start + sc.time_range * sample_1d(tab, spp, s, scr, 0);
+    float l0 = sample_2d(tab, spp, 0, s, scr, 1), l1 = sample_2d(tab, spp, 1, s, scr, 1);
+    f3 o, d;
+    camera_ray(sc.cam, uvx, uvy, l0, l1, &o, &d);
+    pool.ox[P] = o.x; pool.oy[P] = o.y; pool.oz[P] = o.z;
+    pool.dx[P] = d.x; pool.dy[P] = d.y; pool.dz[P] = d.z;
+    pool.time[P] = time;
+    pool.lr[P] = 0.0f; pool.lg[P] = 0.0f; pool.lb[P] = 0.0f; // WRay::new: radiance 0, throughput 1
+    pool.tr[P] = 1.0f; pool.tg[P] = 1.0f; pool.tb[P] = 1.0f;
+    pool.pix[P] = pix;
+    pool.samp[P] = s;
+    q[P] = P;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a10/a11/a13: HitableStore::add_hits (src/hitable.rs:170-210) for one queue entry per thread.
+// Writes t + object into the pool, the object per entry, and the per-group object histogram that
+// the bin scan consumes (wave ballot, no atomics).
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, uint32_t depth, const uint32_t* __restrict__ q,
+                                                 uint32_t n_entries, Pool pool, uint8_t* __restrict__ ent_obj,
+                                                 uint8_t* __restrict__ grp_cnt, unsigned long long* __restrict__ evals_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return; // n_entries is a multiple of 64: whole waves exit together
+    const DScene& sc = *scp;
+    const uint32_t P = q[i];
+    uint32_t obj = OBJ_NONE;
+    uint32_t evals = 0;
+    if (P != INVALID) {
+        f3 o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
+        f3 d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
+        Thr th = make_thr(sc, depth);
+        float t;
+        closest_hit<COUNT>(sc, o, d, th, &t, &obj, evals);
+        pool.hit_t[P] = t;
+        pool.hit_obj[P] = (uint8_t)obj;
+    }
+    ent_obj[i] = (uint8_t)obj;
+    const uint32_t g = i >> 6, lane = lane_id();
+    for (uint32_t c = 0; c < sc.n_hitables; c++) {
+        uint64_t m = __ballot(obj == c);
+        if (lane == c) grp_cnt[g * SCAN_NC_BIN + c] = (uint8_t)__popcll(m);
+    }
+    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one u32 per thread (256 threads = 4 waves)
+// ------------------------------------------------------------------------------------------------
+RD uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave_tot, uint32_t* total) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t n = __shfl_up(inc, off);
+        if (lane >= (uint32_t)off) inc += n;
+    }
+    if (lane == 63) lds_wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        uint32_t wt = lds_wave_tot[w];
+        if (w < wave) base += wt;
+        tot += wt;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a14 (bins) / a26 (repack): per-tile stable offsets.  One block per tile walks the tile's groups
+// and turns per-group class counts into tile-relative output bases:
+//     out slot = class_offset[c] + (#entries of class c in earlier groups) [+ rank inside the group]
+// class_offset pads every class to a multiple of 'pad' (4 for object bins = packets; 1 for the
+// survivor repack, whose x4 padding rays in the reference are invalid and never binned).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scan_tile(uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* __restrict__ grp_cnt,
+                                                    const uint32_t* __restrict__ tile_grp_begin, const uint32_t* __restrict__ tile_grp_count,
+                                                    uint32_t* __restrict__ grp_base, uint32_t* __restrict__ grp_tile,
+                                                    uint32_t* __restrict__ tile_total, uint32_t* __restrict__ tile_valid) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_run[SCAN_NC_BIN];
+    __shared__ uint32_t s_off[SCAN_NC_BIN];
+    const uint32_t k = blockIdx.x;
+    const uint32_t gb = tile_grp_begin[k], gc = tile_grp_count[k];
+    if (threadIdx.x < SCAN_NC_BIN) s_run[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < gc; base += 256) {
+        const uint32_t gi = base + threadIdx.x;
+        const bool in = gi < gc;
+        const uint32_t g = gb + gi;
+        if (in) grp_tile[g] = k;
+        for (uint32_t c = 0; c < nclass; c++) {
+            uint32_t v = in ? grp_cnt[g * stride + c] : 0u;
+            uint32_t tot;
+            uint32_t ex = block_excl_scan(v, s_wave, &tot);
+            if (in) grp_base[g * stride + c] = s_run[c] + ex; // class-relative for now
+            __syncthreads();
+            if (threadIdx.x == 0) s_run[c] += tot;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        uint32_t off = 0, valid = 0;
+        for (uint32_t c = 0; c < nclass; c++) {
+            s_off[c] = off;
+            valid += s_run[c];
+            off += (s_run[c] + pad - 1) / pad * pad;
+        }
+        tile_total[k] = off;
+        tile_valid[k] = valid;
+    }
+    __syncthreads();
+    for (uint32_t gi = threadIdx.x; gi < gc; gi += 256)
+        for (uint32_t c = 0; c < nclass; c++) grp_base[(gb + gi) * stride + c] += s_off[c];
+}
+
+// prefix over the tiles of the batch: where each tile's (64-padded) output segment starts.
+// totals[0] = output groups, totals[1] = valid entries.
+__global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const uint32_t* __restrict__ tile_total,
+                                                       const uint32_t* __restrict__ tile_valid, uint32_t* __restrict__ tile_out_base,
+                                                       uint32_t* __restrict__ out_grp_begin, uint32_t* __restrict__ out_grp_count,
+                                                       uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_vsum[16];
+    __shared__ uint32_t s_run, s_valid;
+    if (threadIdx.x == 0) { s_run = 0; s_valid = 0; }
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t k = base + threadIdx.x;
+        const bool in = k < n_tiles;
+        uint32_t groups = in ? (tile_total[k] + 63u) / 64u : 0u;
+        uint32_t valid = in ? tile_valid[k] : 0u;
+        uint32_t inc = groups, vs = valid;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t n = __shfl_up(inc, off);
+            if (lane >= (uint32_t)off) inc += n;
+            vs += __shfl_xor(vs, off); // butterfly sum (all lanes get the wave total)
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        if (lane == 0) s_vsum[wave] = vs;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0, vtot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            uint32_t wt = s_wave[w];
+            if (w < wave) wbase += wt;
+            tot += wt;
+            vtot += s_vsum[w];
+        }
+        const uint32_t run = s_run;
+        if (in) {
+            uint32_t begin = run + wbase + inc - groups;
+            out_grp_begin[k] = begin;
+            out_grp_count[k] = groups;
+            tile_out_base[k] = begin * 64u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_run = run + tot; s_valid += vtot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = s_run; totals[1] = s_valid; }
+}
+
+// stable scatter of the queue into object bins (a14)
+__global__ void __launch_bounds__(256) k_bin_scatter(uint32_t nclass, const uint32_t* __restrict__ q, const uint8_t* __restrict__ ent_obj,
+                                                      const uint32_t* __restrict__ grp_base, const uint32_t* __restrict__ grp_tile,
+                                                      const uint32_t* __restrict__ tile_out_base, uint32_t n_entries,
+                                                      uint32_t* __restrict__ bq) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    const uint32_t g = i >> 6;
+    const uint32_t obj = ent_obj[i];
+    uint32_t rank = 0;
+    for (uint32_t c = 0; c < nclass; c++) {
+        uint64_t m = __ballot(obj == c);
+        if (obj == c) rank = mbcnt(m);
+    }
+    if (obj == OBJ_NONE) return;
+    const uint32_t dst = tile_out_base[grp_tile[g]] + grp_base[g * SCAN_NC_BIN + obj] + rank;
+    bq[dst] = q[i];
+}
+
+// stable compaction of the survivors of a shade pass into the next ray queue (a26)
+__global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restrict__ bq, const uint8_t* __restrict__ alive,
+                                                          const uint32_t* __restrict__ grp_base, const uint32_t* __restrict__ grp_tile,
+                                                          const uint32_t* __restrict__ tile_out_base, uint32_t n_slots,
+                                                          uint32_t* __restrict__ qn) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_slots) return;
+    const uint32_t g = j >> 6;
+    const bool a = alive[j] != 0;
+    const uint32_t rank = mbcnt(__ballot(a));
+    if (!a) return;
+    qn[tile_out_base[grp_tile[g]] + grp_base[g] + rank] = bq[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// a15-a24: shading info + PathTracingIntegrator::integrate (src/integrator.rs:47-204) for one packet
+// lane per thread.  Slots 4k..4k+3 of the binned queue are one reference packet; the only cross-lane
+// data are the light indices each lane draws from ITS OWN 1-D sample (src/integrator.rs:76-82,
+// 100-110), exchanged with wave shuffles.  Padding lanes use sample 0 / scramble 0
+// (Ray::new_invalid, src/ray.rs:54-66) and still contribute their pick.
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
+                                                uint32_t depth, const uint32_t* __restrict__ bq, uint32_t n_slots, Pool pool,
+                                                uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt,
+                                                unsigned long long* __restrict__ evals_out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_slots) return; // multiple of 64
+    const DScene& sc = *scp;
+    const uint32_t lane = lane_id();
+    const uint32_t P = bq[j];
+    const bool valid = P != INVALID;
+    const uint32_t spp = sc.spp, n1 = sc.n1, n2h = sc.n2 / 2, nl = sc.n_lights, VM = sc.vm;
+    uint32_t sample = 0, pix = 0;
+    float scr = 0.0f;
+    if (valid) { sample = pool.samp[P]; pix = pool.pix[P]; scr = scramble[pix]; }
+    const uint32_t set1 = 1 + depth * n1;      // 1-D set of samples_1d[0] at this depth, src/film.rs:568-574
+    const uint32_t set2 = 2 + depth * n2h;     // 2-D set of samples_2d[0..1], src/film.rs:579-589
+    // light picks: each lane draws an index from ITS 1-D sample; the packet's four picks are packed
+    // 4 bits each (n_lights <= 16) so the rolled loops below need no register arrays.
+    uint32_t surf_picks = 0;
+    unsigned long long vol_picks = 0;
+    if (nl > 0) {
+        const uint32_t base = lane & ~3u;
+        for (uint32_t k = 0; k < 1 + VM; k++) {
+            uint32_t mine = light_index(sample_1d(tab, spp, sample, scr, set1 + k), nl);
+            uint32_t packed = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) packed |= (uint32_t)__shfl(mine, base + i) << (4 * i);
+            if (k == 0) surf_picks = packed;
+            else vol_picks |= (unsigned long long)packed << (16 * (k - 1));
+        }
+    }
+    bool is_alive = false;
+    uint32_t evals = 0;
+    if (valid) {
+        f3 o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
+        f3 d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
+        f3 rad = f3{pool.lr[P], pool.lg[P], pool.lb[P]};
+        f3 thr = f3{pool.tr[P], pool.tg[P], pool.tb[P]};
+        const float t = pool.hit_t[P];
+        // object of this slot: recover from the hit stage
+        const uint32_t obj = pool.hit_obj[P];
+        const DHitable& h = sc.h[obj];
+        const DMaterial& mat = sc.m[h.material];
+        // get_shading_info
+        f3 point = muladd3(d, t, o); // WHit::point -> Ray::point_at
+        f3 normal;
+        float offset_by;
+        if (h.kind == RAYN_HITABLE_SPHERE) { // src/sphere.rs:73-86
+            normal = normalized(point - h.center);
+            offset_by = 0.0f;
+        } else { // src/sdf.rs:85-101
+            Thr th = make_thr(sc, depth);
+            float hps = fmaxs(0.0001f, sc.detail_scale * thr_at(th, t));
+            normal = sdf_normal<COUNT>(h, point, hps, evals);
+            offset_by = hps;
+        }
+        const Basis basis = orthonormal_basis(normal);
+        const f3 wo = -d;
+        const float vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
+        rad = rad + bsdf_le(mat, wo) * thr * vol_T;
+        const bool receives = mat.receives_light != 0;
+        if (receives && nl > 0) {
+            const float corr = (float)nl / 4.0f;
+            for (uint32_t i = 0; i < 4; i++) { // surface_sample_one_light, src/integrator.rs:207-240
+                const DLight& L = sc.l[(surf_picks >> (4 * i)) & 15u];
+                float u0 = sample_2d(tab, spp, 0, sample, scr, set2 + i), u1 = sample_2d(tab, spp, 1, sample, scr, set2 + i);
+                f3 end_point; float pdf;
+                light_sample(L, u0, u1, point, &end_point, &pdf);
+                f3 wi = end_point - point;
+                float dist = mag(wi);
+                wi = wi / dist;
+                f3 occlude_point = point + normal * signum(dot(normal, wi)) * offset_by;
+                float occ = test_occluded<COUNT>(sc, occlude_point, end_point, evals);
+                f3 f = bsdf_f(mat, wo, wi, normal) * fmaxs(dot(normal, wi), 0.0f);
+                float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dist) : 1.0f;
+                f3 li = L.emission * f * tr * occ / pdf;
+                rad = rad + li * thr * corr * vol_T;
+            }
+        }
+        if (sc.has_scatter && nl > 0) { // src/integrator.rs:96-132
+            const float corr = (float)nl / 4.0f / (float)VM;
+            const float vsample = sample_1d(tab, spp, sample, scr, set1 + 1); // samples_1d[1] for every march
+            for (uint32_t march = 0; march < VM; march++) {
+                for (uint32_t i = 0; i < 4; i++) { // volume_sample_one_light :242-281
+                    const DLight& L = sc.l[(uint32_t)(vol_picks >> (16 * march + 4 * i)) & 15u];
+                    const uint32_t set = set2 + 4 + 4 * march + i; // comps 8+8*march+2i, +1
+                    float u0 = sample_2d(tab, spp, 0, sample, scr, set), u1 = sample_2d(tab, spp, 1, sample, scr, set);
+                    float vdist, vpdf;
+                    light_sample_volume(L, vsample, o, d, t, &vdist, &vpdf);
+                    f3 sp = o + d * vdist;
+                    f3 end_point; float lpdf;
+                    light_sample(L, u0, u1, sp, &end_point, &lpdf);
+                    float dl = mag(end_point - sp);
+                    float occ = test_occluded<COUNT>(sc, sp, end_point, evals);
+                    float f = 1.0f / (4.0f * PI_F);
+                    float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dl) : 1.0f;
+                    f3 li = L.emission * f * tr * occ / (vpdf * lpdf);
+                    float tr2 = sc.has_extinct ? dm_expf(-sc.rho_t * vdist) : 1.0f;
+                    rad = rad + li * thr * corr * sc.rho_s * tr2;
+                }
+            }
+        }
+        uint32_t key = (depth << 26) | j;
+        if (receives) {
+            const uint32_t bset = set2 + 4 + 4 * VM; // comps 8+8*VM .. +3
+            float s3 = sample_1d(tab, spp, sample, scr, set1 + 3), s4 = sample_1d(tab, spp, sample, scr, set1 + 4);
+            Scatter se = bsdf_scatter(mat, wo, normal, basis, s3, sample_2d(tab, spp, 0, sample, scr, bset),
+                                      sample_2d(tab, spp, 1, sample, scr, bset), sample_2d(tab, spp, 0, sample, scr, bset + 1),
+                                      sample_2d(tab, spp, 1, sample, scr, bset + 1));
+            float ndl = __builtin_fabsf(dot(se.wi, normal));
+            f3 nthr = thr * vol_T * se.f * ndl / se.pdf;
+            float rr = 0.0f;
+            if (depth > 2) {
+                rr = fmaxs(1.0f - component_max(thr), 0.05f);
+                nthr = nthr / (1.0f - rr);
+            }
+            if (depth == 0) { // Alpha + WorldNormal AOVs, src/integrator.rs:161-169
+                pool.n0x[P] = normal.x; pool.n0y[P] = normal.y; pool.n0z[P] = normal.z;
+                pool.obj0[P] = (uint8_t)obj;
+            }
+            if (depth >= sc.max_bounces || s4 < rr) {
+                pool.term_key[P] = key; // ChannelSample::Color(ray.radiance)
+            } else {
+                if (!any_nan(nthr)) thr = nthr;
+                f3 no = point + normal * signum(dot(normal, se.wi)) * offset_by; // create_rays, src/hitable.rs:42-47
+                pool.ox[P] = no.x; pool.oy[P] = no.y; pool.oz[P] = no.z;
+                pool.dx[P] = se.wi.x; pool.dy[P] = se.wi.y; pool.dz[P] = se.wi.z;
+                pool.tr[P] = thr.x; pool.tg[P] = thr.y; pool.tb[P] = thr.z;
+                is_alive = true;
+            }
+        } else {
+            pool.term_key[P] = key | (depth == 0 ? 0x80000000u : 0u); // Background at depth 0, else Color
+        }
+        pool.lr[P] = rad.x; pool.lg[P] = rad.y; pool.lb[P] = rad.z;
+    }
+    alive[j] = is_alive ? 1 : 0;
+    uint64_t m = __ballot(is_alive);
+    if (lane == 0) bgrp_cnt[j >> 6] = (uint8_t)__popcll(m);
+    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a25/a27: Tile::add_sample + tile_finished (src/film.rs:54-61,82-98,167-172,660-691).
+// The reference adds a pixel's samples serially in emission order = (depth, packet slot); float
+// addition is not associative, so this kernel replays exactly that order: one wave per pixel sorts
+// the pixel's spp paths by termination key in LDS (bitonic) and three lanes (r,g,b) accumulate them
+// sequentially.  Alpha/WorldNormal are depth-0 samples, ordered (object, sample).
+// ------------------------------------------------------------------------------------------------
+RD void bitonic_sort_lds(uint32_t* key, uint32_t* val, uint32_t n) {
+    for (uint32_t k = 2; k <= n; k <<= 1)
+        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                uint32_t l = i ^ jj;
+                if (l > i) {
+                    bool up = (i & k) == 0;
+                    uint32_t a = key[i], b = key[l];
+                    if ((a > b) == up) {
+                        key[i] = b; key[l] = a;
+                        uint32_t t = val[i]; val[i] = val[l]; val[l] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
+                                                 float* __restrict__ out_color, float* __restrict__ out_alpha,
+                                                 float* __restrict__ out_background, float* __restrict__ out_normal, uint32_t n_sort) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* key = smem;
+    uint32_t* val = smem + n_sort;
+    const DScene& sc = *scp;
+    const DTile tile = tiles[blockIdx.y];
+    const uint32_t lpix = blockIdx.x;
+    if (lpix >= tile.ew * tile.eh) return;
+    const uint32_t spp = sc.spp;
+    const uint32_t P0 = tile.pool_base + lpix * spp;
+    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
+    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
+    const float n = (float)spp;
+    // ---- Color / Background in (depth, slot) order
+    for (uint32_t i = threadIdx.x; i < n_sort; i += 64) {
+        uint32_t k = INVALID;
+        if (i < spp) { uint32_t tk = pool.term_key[P0 + i]; if (tk != INVALID) k = tk & 0x7FFFFFFFu; }
+        key[i] = k;
+        val[i] = i;
+    }
+    __syncthreads();
+    bitonic_sort_lds(key, val, n_sort);
+    if (threadIdx.x < 3) {
+        const float* src = threadIdx.x == 0 ? pool.lr : (threadIdx.x == 1 ? pool.lg : pool.lb);
+        float c = 0.0f, b = 0.0f;
+        for (uint32_t e = 0; e < spp; e++) {
+            if (key[e] == INVALID) break;
+            const uint32_t P = P0 + val[e];
+            const float v = src[P];
+            if (pool.term_key[P] & 0x80000000u) b += v; else c += v;
+        }
+        out_color[3 * fi + threadIdx.x] = c / n;
+        out_background[3 * fi + threadIdx.x] = b / n;
+    }
+    __syncthreads();
+    // ---- Alpha / WorldNormal: depth-0 packets are object-major, then queue (= sample) order
+    for (uint32_t i = threadIdx.x; i < n_sort; i += 64) {
+        uint32_t k = INVALID;
+        if (i < spp) { uint32_t ob = pool.obj0[P0 + i]; if (ob != OBJ_NONE) k = (ob << 16) | i; }
+        key[i] = k;
+        val[i] = i;
+    }
+    __syncthreads();
+    bitonic_sort_lds(key, val, n_sort);
+    if (threadIdx.x < 4) {
+        const float* src = threadIdx.x == 0 ? pool.n0x : (threadIdx.x == 1 ? pool.n0y : pool.n0z);
+        float a = 0.0f;
+        for (uint32_t e = 0; e < spp; e++) {
+            if (key[e] == INVALID) break;
+            a += threadIdx.x == 3 ? 1.0f : src[P0 + val[e]];
+        }
+        if (threadIdx.x == 3) out_alpha[fi] = a / n;
+        else out_normal[3 * fi + threadIdx.x] = a / n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// test probes (called through the C ABI by tests only): per-lane primitives on arbitrary inputs
+// ------------------------------------------------------------------------------------------------
+__global__ void k_probe_dist(const DScene* __restrict__ scp, uint32_t hit_index, const float* __restrict__ pts, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ev = 0;
+    out[i] = sdf_dist<false>(scp->h[hit_index], f3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, ev);
+}
+__global__ void k_probe_closest(const DScene* __restrict__ scp, uint32_t depth, const float* __restrict__ org, const float* __restrict__ dir,
+                                float* __restrict__ out_t, uint32_t* __restrict__ out_obj, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ev = 0, obj;
+    float t;
+    closest_hit<false>(*scp, f3{org[3 * i], org[3 * i + 1], org[3 * i + 2]}, f3{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]},
+                       make_thr(*scp, depth), &t, &obj, ev);
+    out_t[i] = t;
+    out_obj[i] = obj == OBJ_NONE ? INVALID : obj;
+}
+__global__ void k_probe_occluded(const DScene* __restrict__ scp, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ev = 0;
+    out[i] = test_occluded<false>(*scp, f3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, f3{b[3 * i], b[3 * i + 1], b[3 * i + 2]}, ev);
+}
+__global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+    case 0: r = dm_expf(a[i]); break;
+    case 1: r = dm_sinf(a[i]); break;
+    case 2: r = dm_cosf(a[i]); break;
+    case 3: r = dm_tanf(a[i]); break;
+    case 4: r = dm_atan2f(a[i], b[i]); break;
+    default: r = dm_powf(a[i], b[i]); break;
+    }
+    out[i] = r;
+}
+
+// ---- launch wrappers (declared in kernels.h) -----------------------------------------------------
+static inline dim3 grid_for(uint32_t n, uint32_t block) { return dim3((n + block - 1) / block); }
+
+void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
+                   Pool pool, uint32_t* q, uint32_t n_pool) {
+    hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool);
+}
+void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
+                   uint8_t* ent_obj, uint8_t* grp_cnt, unsigned long long* evals) {
+    if (count) hipLaunchKernelGGL(k_extend<true>, grid_for(n_entries, 256), dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, grp_cnt, evals);
+    else hipLaunchKernelGGL(k_extend<false>, grid_for(n_entries, 256), dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, grp_cnt, evals);
+}
+void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
+                      const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
+                      uint32_t* tile_valid) {
+    hipLaunchKernelGGL(k_scan_tile, dim3(n_tiles), dim3(256), 0, s, nclass, stride, pad, grp_cnt, tgb, tgc, grp_base, grp_tile, tile_total, tile_valid);
+}
+void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
+                        uint32_t* ogb, uint32_t* ogc, uint32_t* totals) {
+    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, s, n_tiles, tile_total, tile_valid, tile_out_base, ogb, ogc, totals);
+}
+void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
+                        const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq) {
+    hipLaunchKernelGGL(k_bin_scatter, grid_for(n_entries, 256), dim3(256), 0, s, nclass, q, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
+}
+void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
+                  uint32_t n_slots, Pool pool, uint8_t* alive, uint8_t* bgrp_cnt, unsigned long long* evals) {
+    if (count) hipLaunchKernelGGL(k_shade<true>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, alive, bgrp_cnt, evals);
+    else hipLaunchKernelGGL(k_shade<false>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, alive, bgrp_cnt, evals);
+}
+void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
+                            const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn) {
+    hipLaunchKernelGGL(k_compact_scatter, grid_for(n_slots, 256), dim3(256), 0, s, bq, alive, grp_base, grp_tile, tile_out_base, n_slots, qn);
+}
+void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
+                    float* out_color, float* out_alpha, float* out_background, float* out_normal) {
+    uint32_t n_sort = 1;
+    while (n_sort < spp) n_sort <<= 1;
+    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 8, s, sc, tiles, pool, out_color, out_alpha, out_background,
+                       out_normal, n_sort);
+}
+void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {
+    hipLaunchKernelGGL(k_probe_dist, grid_for(n, 256), dim3(256), 0, s, sc, hit_index, pts, out, n);
+}
+void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n) {
+    hipLaunchKernelGGL(k_probe_closest, grid_for(n, 256), dim3(256), 0, s, sc, depth, org, dir, out_t, out_obj, n);
+}
+void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n) {
+    hipLaunchKernelGGL(k_probe_occluded, grid_for(n, 256), dim3(256), 0, s, sc, a, b, out, n);
+}
+void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const float* b, float* out, uint32_t n) {
+    hipLaunchKernelGGL(k_probe_detmath, grid_for(n, 256), dim3(256), 0, s, op, a, b, out, n);
+}
+
+} // namespace rayn

@@ -1,0 +1,556 @@
+// rayn_hip.hip — C ABI (include/rayn_hip.h) and host driver of the wavefront renderer.
+//
+// Replaces the body of Film::render_frame_into (src/film.rs:382-628): builds the reference's tile
+// list, groups tiles into batches that fit the path pool, and for every batch runs
+//   ray-gen -> { extend -> bin (scan+scatter) -> shade -> repack (scan+scatter) } per depth -> resolve
+// on one HIP stream.  The only host<->device traffic inside a frame is two 8-byte queue-size
+// readbacks per depth (they size the next launches).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/rayn_detmath.h"
+#include "../../include/rayn_hip.h"
+#include "kernels.h"
+
+using namespace rayn;
+
+namespace {
+
+enum ProfClass { PC_RAYGEN = 0, PC_EXTEND, PC_BIN, PC_SHADE, PC_COMPACT, PC_RESOLVE, PC_COUNT };
+
+struct ProfRec { int cls; hipEvent_t a, b; };
+
+struct Arena { // one device allocation carved into 256-byte aligned pieces
+    char* base = nullptr; size_t cap = 0, off = 0;
+    template <typename T> T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        T* p = (T*)(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct TileRect { uint32_t x0, y0, x1, y1; };
+
+} // namespace
+
+struct rayn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_world = false;
+    rayn_world_desc world;
+    DScene* d_scene = nullptr;
+    Arena arena;
+    uint32_t* h_totals = nullptr; // pinned
+    unsigned long long* d_evals = nullptr;
+    rayn_stats stats;
+    unsigned long long evals_extend = 0, evals_shade = 0;
+    bool profiling = false, counting = false;
+    size_t batch_paths = (size_t)1 << 25;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(rayn_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(ctx, RAYN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// tile list exactly as render_frame_into builds it, src/film.rs:399-427 (x-major, incl. the
+// (res + res%tile)/tile under-coverage quirk)
+std::vector<TileRect> build_tiles(uint32_t W, uint32_t H, uint32_t tw, uint32_t th) {
+    std::vector<TileRect> t;
+    uint32_t nx = (W + W % tw) / tw, ny = (H + H % th) / th;
+    for (uint32_t tx = 0; tx < nx; tx++)
+        for (uint32_t ty = 0; ty < ny; ty++) {
+            uint32_t sx = tx * tw, sy = ty * th;
+            t.push_back(TileRect{sx, sy, std::min(sx + tw, W), std::min(sy + th, H)});
+        }
+    return t;
+}
+
+f3 to3(rayn_vec3 v) { return f3{v.x, v.y, v.z}; }
+
+int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params& p, DScene* out) {
+    DScene& s = *out;
+    memset(&s, 0, sizeof s);
+    if (w.n_hitables > RAYN_MAX_HITABLES || w.n_materials > RAYN_MAX_MATERIALS || w.n_lights > RAYN_MAX_LIGHTS)
+        return fail(ctx, RAYN_ERR_INVALID_ARG, "world exceeds fixed capacities");
+    s.n_hitables = w.n_hitables; s.n_materials = w.n_materials; s.n_lights = w.n_lights;
+    for (uint32_t i = 0; i < w.n_hitables; i++) {
+        const rayn_hitable& h = w.hitables[i];
+        DHitable& d = s.h[i];
+        if (h.material >= w.n_materials) return fail(ctx, RAYN_ERR_INVALID_ARG, "hitable references a missing material");
+        d.kind = h.kind; d.material = h.material; d.sdf_kind = h.sdf_kind; d.iterations = h.iterations;
+        d.center = to3(h.center);
+        d.radius_sq = h.radius * h.radius;
+        d.box_l = h.box_side;
+        d.min_rad_sq = h.min_radius * h.min_radius;
+        d.fixed_rad_sq = h.fixed_radius * h.fixed_radius;
+        d.scale = h.scale;
+        d.sdf_radius = h.sdf_radius;
+        if (h.kind == RAYN_HITABLE_TRACED_SDF) {
+            s.n_sdf++;
+            if (h.sdf_kind != RAYN_SDF_SPHERE && h.sdf_kind != RAYN_SDF_MANDELBOX) return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown sdf_kind");
+        } else if (h.kind != RAYN_HITABLE_SPHERE) return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown hitable kind");
+    }
+    for (uint32_t i = 0; i < w.n_materials; i++) {
+        const rayn_material& m = w.materials[i];
+        DMaterial& d = s.m[i];
+        if (m.kind > RAYN_MAT_EMISSIVE) return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown material kind");
+        d.kind = m.kind; d.a = to3(m.a); d.b = to3(m.b); d.exponent = m.exponent;
+        d.receives_light = (m.kind == RAYN_MAT_SKY || m.kind == RAYN_MAT_EMISSIVE) ? 0u : 1u; // BSDF::receives_light
+    }
+    for (uint32_t i = 0; i < w.n_lights; i++) {
+        s.l[i].pos = to3(w.lights[i].pos); s.l[i].rad = w.lights[i].rad; s.l[i].emission = to3(w.lights[i].emission);
+    }
+    const rayn_camera& c = w.camera;
+    DCamera& dc = s.cam;
+    dc.kind = c.kind; dc.origin = to3(c.origin); dc.at = to3(c.at); dc.up = to3(c.up); dc.focus = to3(c.focus); dc.aperture = c.aperture;
+    if (c.kind == RAYN_CAM_ORTHOGRAPHIC) { // OrthographicCamera::new, src/camera.rs:228-240
+        float aspect = c.res_w / c.res_h;
+        float sx = c.vfov_or_size * aspect, sy = c.vfov_or_size;
+        float pixel_size = c.vfov_or_size / c.res_h;
+        dc.half_w = sx / 2.0f; dc.half_h = sy / 2.0f; dc.full_w = sx; dc.full_h = sy;
+        dc.half_pixel_size = pixel_size / 2.0f;
+    } else if (c.kind == RAYN_CAM_PINHOLE || c.kind == RAYN_CAM_THIN_LENS) { // ::new, src/camera.rs:53-72,134-157
+        float theta = c.vfov_or_size * 3.14159265358979323846f / 180.0f;
+        float half_height = dm_tanf(theta / 2.0f);
+        float aspect = c.res_w / c.res_h;
+        float half_width = aspect * half_height;
+        dc.half_pixel_size = half_height / c.res_h;
+        dc.half_w = half_width; dc.half_h = half_height; dc.full_w = half_width; dc.full_h = half_height;
+    } else return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown camera kind");
+    s.has_scatter = w.has_scattering; s.has_extinct = w.has_extinction; s.rho_s = w.coeff_scattering; s.rho_t = w.coeff_extinction;
+    s.width = p.width; s.height = p.height; s.spp = p.samples * 4; s.max_bounces = p.max_bounces; s.vm = p.volume_marches;
+    s.max_marches = p.max_marches; s.max_vis_marches = p.max_vis_marches;
+    s.n1 = 3 + p.volume_marches; s.n2 = 12 + 8 * p.volume_marches;
+    s.time_start = p.time_start; s.time_range = p.time_end - p.time_start;
+    s.detail_scale = p.sdf_detail_scale; s.t_max = p.world_radius * 2.0f;
+    s.ndc_x = 1.0f / (float)p.width; s.ndc_y = 1.0f / (float)p.height;
+    return RAYN_OK;
+}
+
+int validate(rayn_ctx* ctx, const rayn_frame_params* p) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    if (!p) return fail(ctx, RAYN_ERR_INVALID_ARG, "null frame params");
+    if (!ctx->have_world) return fail(ctx, RAYN_ERR_NO_WORLD, "rayn_hip_upload_world has not been called");
+    if (!p->width || !p->height || !p->samples || !p->tile_w || !p->tile_h) return fail(ctx, RAYN_ERR_INVALID_ARG, "zero-sized frame, tile or sample count");
+    if (p->volume_marches < 2 || p->volume_marches > 4) return fail(ctx, RAYN_ERR_INVALID_ARG, "volume_marches must be in [2,4] (samples_1d[3],[4] are indexed, src/integrator.rs:138,175)");
+    if (p->max_bounces > 30) return fail(ctx, RAYN_ERR_INVALID_ARG, "max_bounces > 30 does not fit the 5-bit depth field of the termination key");
+    if (p->samples * 4 > 65535) return fail(ctx, RAYN_ERR_INVALID_ARG, "spp > 65535 unsupported");
+    if (p->tile_w * p->tile_h > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile larger than 1024 pixels unsupported");
+    return RAYN_OK;
+}
+
+hipEvent_t get_event(rayn_ctx* ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct Timed { // brackets one launch with events when profiling is on
+    rayn_ctx* ctx; hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Timed(rayn_ctx* c, hipStream_t st, int cl) : ctx(c), s(st), cls(cl) {
+        if (ctx->profiling) { a = get_event(ctx); b = get_event(ctx); if (a) (void)hipEventRecord(a, s); }
+    }
+    ~Timed() {
+        if (ctx->profiling && a && b) { (void)hipEventRecord(b, s); ctx->prof.push_back(ProfRec{cls, a, b}); }
+    }
+};
+
+void collect_profile(rayn_ctx* ctx) {
+    double ms[PC_COUNT] = {0};
+    for (auto& r : ctx->prof) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
+        ctx->event_pool.push_back(r.a);
+        ctx->event_pool.push_back(r.b);
+    }
+    ctx->prof.clear();
+    ctx->stats.ms_raygen = ms[PC_RAYGEN]; ctx->stats.ms_extend = ms[PC_EXTEND]; ctx->stats.ms_bin = ms[PC_BIN];
+    ctx->stats.ms_shade = ms[PC_SHADE]; ctx->stats.ms_compact = ms[PC_COMPACT]; ctx->stats.ms_resolve = ms[PC_RESOLVE];
+}
+
+struct BatchTile { uint32_t tile_index; DTile d; };
+
+int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, const float* d_s2, const float* d_scr, const float* d_fis,
+                  float* d_color, float* d_alpha, float* d_bg, float* d_normal, hipStream_t stream) {
+    int rc = validate(ctx, p);
+    if (rc) return rc;
+    if (!d_s1 || !d_s2 || !d_scr || !d_fis || !d_color || !d_alpha || !d_bg || !d_normal) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
+    HIPCHK(hipSetDevice(ctx->device));
+    DScene hs;
+    rc = build_scene(ctx, ctx->world, *p, &hs);
+    if (rc) return rc;
+    const uint32_t spp = hs.spp;
+    const uint32_t step = p->tile_step ? p->tile_step : 1;
+    if (p->tile_first >= step) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile_first must be < tile_step");
+
+    // ---- plan: owned tiles -> batches
+    std::vector<TileRect> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
+    std::vector<std::vector<BatchTile>> batches;
+    size_t max_pool = 0, max_tiles = 0;
+    uint32_t max_tile_pixels = 0;
+    {
+        std::vector<BatchTile> cur;
+        size_t pool = 0;
+        for (uint32_t k = p->tile_first; k < tiles.size(); k += step) {
+            const TileRect& t = tiles[k];
+            uint32_t ew = t.x1 - t.x0, eh = t.y1 - t.y0;
+            if (!ew || !eh) continue;
+            size_t n = (size_t)ew * eh * spp, na = (n + 63) & ~(size_t)63;
+            if (!cur.empty() && pool + na > ctx->batch_paths) {
+                max_pool = std::max(max_pool, pool); max_tiles = std::max(max_tiles, cur.size());
+                batches.push_back(std::move(cur)); cur.clear(); pool = 0;
+            }
+            BatchTile bt; bt.tile_index = k;
+            bt.d = DTile{t.x0, t.y0, ew, eh, (uint32_t)pool, (uint32_t)n, {0, 0}};
+            cur.push_back(bt);
+            pool += na;
+            max_tile_pixels = std::max(max_tile_pixels, ew * eh);
+        }
+        if (!cur.empty()) { max_pool = std::max(max_pool, pool); max_tiles = std::max(max_tiles, cur.size()); batches.push_back(std::move(cur)); }
+    }
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->evals_extend = ctx->evals_shade = 0;
+    if (batches.empty()) return RAYN_OK;
+
+    // ---- device memory: one arena sized for the largest batch
+    const size_t CAP = max_pool;                                   // pool slots
+    const size_t QCAP = CAP + max_tiles * 64;                      // ray queue slots (tile tails)
+    const size_t BCAP = CAP + max_tiles * (SCAN_NC_BIN * 3 + 64);  // binned slots (x4 bin padding + tails)
+    if (BCAP >= ((size_t)1 << 26)) return fail(ctx, RAYN_ERR_INVALID_ARG, "batch too large for the 26-bit slot field; lower RAYN_HIP_BATCH_PATHS");
+    const size_t QG = QCAP / 64 + 1, BG = BCAP / 64 + 1;
+    size_t need = 0;
+    auto acc = [&](size_t n, size_t sz) { need += (n * sz + 255) & ~(size_t)255; };
+    acc(CAP, 4 * 14); acc(CAP, 1); acc(CAP, 8); acc(CAP, 4); acc(CAP, 12); acc(CAP, 1);           // pool (each array separately below)
+    need += 256 * 32;                                                                              // alignment slack for the separate pool arrays
+    acc(QCAP, 4); acc(QCAP, 4); acc(BCAP, 4); acc(QCAP, 1); acc(BCAP, 1);                          // q, qn, bq, ent_obj, alive
+    acc(QG * SCAN_NC_BIN, 1); acc(QG * SCAN_NC_BIN, 4); acc(QG, 4);                                // grp_cnt, grp_base, grp_tile
+    acc(BG, 1); acc(BG, 4); acc(BG, 4);                                                            // bgrp_*
+    acc(max_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                           // tiles, pgrp_tile
+    for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
+    acc(2, 4);
+    if (need > ctx->arena.cap) {
+        if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
+        ctx->arena.base = nullptr; ctx->arena.cap = 0;
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, need) != hipSuccess) return fail(ctx, RAYN_ERR_OOM, "hipMalloc of the path pool failed (" + std::to_string(need >> 20) + " MiB)");
+        ctx->arena.base = (char*)ptr; ctx->arena.cap = need;
+    }
+    Arena& A = ctx->arena;
+    A.off = 0;
+    Pool pool;
+    pool.ox = A.take<float>(CAP); pool.oy = A.take<float>(CAP); pool.oz = A.take<float>(CAP);
+    pool.dx = A.take<float>(CAP); pool.dy = A.take<float>(CAP); pool.dz = A.take<float>(CAP); pool.time = A.take<float>(CAP);
+    pool.lr = A.take<float>(CAP); pool.lg = A.take<float>(CAP); pool.lb = A.take<float>(CAP);
+    pool.tr = A.take<float>(CAP); pool.tg = A.take<float>(CAP); pool.tb = A.take<float>(CAP);
+    pool.hit_t = A.take<float>(CAP); pool.hit_obj = A.take<uint8_t>(CAP);
+    pool.pix = A.take<uint32_t>(CAP); pool.samp = A.take<uint32_t>(CAP); pool.term_key = A.take<uint32_t>(CAP);
+    pool.n0x = A.take<float>(CAP); pool.n0y = A.take<float>(CAP); pool.n0z = A.take<float>(CAP); pool.obj0 = A.take<uint8_t>(CAP);
+    uint32_t* q = A.take<uint32_t>(QCAP); uint32_t* qn = A.take<uint32_t>(QCAP); uint32_t* bq = A.take<uint32_t>(BCAP);
+    uint8_t* ent_obj = A.take<uint8_t>(QCAP); uint8_t* alive = A.take<uint8_t>(BCAP);
+    uint8_t* grp_cnt = A.take<uint8_t>(QG * SCAN_NC_BIN); uint32_t* grp_base = A.take<uint32_t>(QG * SCAN_NC_BIN); uint32_t* grp_tile = A.take<uint32_t>(QG);
+    uint8_t* bgrp_cnt = A.take<uint8_t>(BG); uint32_t* bgrp_base = A.take<uint32_t>(BG); uint32_t* bgrp_tile = A.take<uint32_t>(BG);
+    DTile* d_tiles = A.take<DTile>(max_tiles); uint32_t* pgrp_tile = A.take<uint32_t>(CAP / 64 + 1);
+    uint32_t* tgbA = A.take<uint32_t>(max_tiles); uint32_t* tgcA = A.take<uint32_t>(max_tiles);
+    uint32_t* tgbB = A.take<uint32_t>(max_tiles); uint32_t* tgcB = A.take<uint32_t>(max_tiles);
+    uint32_t* tile_total = A.take<uint32_t>(max_tiles); uint32_t* tile_valid = A.take<uint32_t>(max_tiles); uint32_t* tile_out_base = A.take<uint32_t>(max_tiles);
+    uint32_t* d_totals = A.take<uint32_t>(2);
+    if (A.off > A.cap) return fail(ctx, RAYN_ERR_OOM, "internal: arena under-sized");
+
+    hipEvent_t ev_a = get_event(ctx), ev_b = get_event(ctx);
+    HIPCHK(hipEventRecord(ev_a, stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_scene, &hs, sizeof hs, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(ctx->d_evals, 0, 16, stream));
+    const Tables tab{d_s1, d_s2, d_fis};
+    const bool count = ctx->counting;
+
+    std::vector<DTile> h_tiles; std::vector<uint32_t> h_pgrp, h_tgb, h_tgc;
+    for (auto& batch : batches) {
+        const uint32_t nt = (uint32_t)batch.size();
+        h_tiles.resize(nt); h_tgb.resize(nt); h_tgc.resize(nt);
+        size_t n_pool = 0;
+        h_pgrp.clear();
+        for (uint32_t i = 0; i < nt; i++) {
+            h_tiles[i] = batch[i].d;
+            uint32_t groups = (batch[i].d.n_paths + 63) / 64;
+            h_tgb[i] = batch[i].d.pool_base / 64; h_tgc[i] = groups;
+            h_pgrp.insert(h_pgrp.end(), groups, i);
+            n_pool += (size_t)groups * 64;
+            ctx->stats.paths += batch[i].d.n_paths;
+        }
+        ctx->stats.tiles += nt; ctx->stats.batches++;
+        // the staging vectors are reused by the next batch: finish these copies before going on
+        HIPCHK(hipMemcpyAsync(d_tiles, h_tiles.data(), nt * sizeof(DTile), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(pgrp_tile, h_pgrp.data(), h_pgrp.size() * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(tgbA, h_tgb.data(), nt * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(tgcA, h_tgc.data(), nt * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+
+        { Timed t(ctx, stream, PC_RAYGEN); launch_raygen(stream, ctx->d_scene, tab, d_scr, d_tiles, pgrp_tile, pool, q, (uint32_t)n_pool); }
+        uint32_t n_entries = (uint32_t)n_pool;
+        uint32_t* qcur = q; uint32_t* qnext = qn;
+        for (uint32_t depth = 0; n_entries > 0; depth++) {
+            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, ctx->d_evals); }
+            ctx->stats.launches_extend++;
+            {
+                Timed t(ctx, stream, PC_BIN);
+                launch_scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid);
+                launch_tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_totals);
+            }
+            HIPCHK(hipMemcpyAsync(ctx->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            const uint32_t n_slots = ctx->h_totals[0] * 64, n_hits = ctx->h_totals[1];
+            ctx->stats.segments += n_hits;
+            if (n_hits == 0) break;
+            if (n_slots > BCAP) return fail(ctx, RAYN_ERR_OOM, "internal: binned queue overflow");
+            {
+                Timed t(ctx, stream, PC_BIN);
+                HIPCHK(hipMemsetAsync(bq, 0xFF, (size_t)n_slots * 4, stream));
+                launch_bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
+            }
+            ctx->stats.queue_bytes += (uint64_t)n_entries * (4 + 1 + 4) + (uint64_t)n_slots * 4;
+            { Timed t(ctx, stream, PC_SHADE); launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, alive, bgrp_cnt, ctx->d_evals + 1); }
+            ctx->stats.launches_shade++;
+            ctx->stats.shaded_slots += n_slots;
+            {
+                Timed t(ctx, stream, PC_COMPACT);
+                launch_scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid);
+                launch_tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_totals);
+            }
+            HIPCHK(hipMemcpyAsync(ctx->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            const uint32_t n_next = ctx->h_totals[0] * 64, n_alive = ctx->h_totals[1];
+            if (n_alive == 0) break;
+            if (n_next > QCAP) return fail(ctx, RAYN_ERR_OOM, "internal: ray queue overflow");
+            {
+                Timed t(ctx, stream, PC_COMPACT);
+                HIPCHK(hipMemsetAsync(qnext, 0xFF, (size_t)n_next * 4, stream));
+                launch_compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, n_slots, qnext);
+            }
+            ctx->stats.queue_bytes += (uint64_t)n_slots * (4 + 1) + (uint64_t)n_next * 4;
+            std::swap(qcur, qnext);
+            n_entries = n_next;
+        }
+        { Timed t(ctx, stream, PC_RESOLVE); launch_resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, d_color, d_alpha, d_bg, d_normal); }
+    }
+    HIPCHK(hipEventRecord(ev_b, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev_a, ev_b);
+    ctx->stats.ms_total = ms;
+    ctx->event_pool.push_back(ev_a); ctx->event_pool.push_back(ev_b);
+    if (ctx->profiling) collect_profile(ctx);
+    if (count) {
+        unsigned long long ev[2] = {0, 0};
+        HIPCHK(hipMemcpy(ev, ctx->d_evals, 16, hipMemcpyDeviceToHost));
+        ctx->evals_extend = ev[0]; ctx->evals_shade = ev[1];
+    }
+    return RAYN_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rayn_hip_create(int device, rayn_ctx** out) {
+    if (!out) return RAYN_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RAYN_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return RAYN_ERR_INVALID_ARG;
+    rayn_ctx* ctx = new rayn_ctx();
+    ctx->device = device;
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_scene, sizeof(DScene)) != hipSuccess || hipMalloc((void**)&ctx->d_evals, 16) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_totals, 16) != hipSuccess) {
+        delete ctx;
+        return RAYN_ERR_HIP;
+    }
+    if (const char* e = getenv("RAYN_HIP_BATCH_PATHS")) { long long v = atoll(e); if (v >= 4096) ctx->batch_paths = (size_t)v; }
+    if (const char* e = getenv("RAYN_HIP_PROFILE")) ctx->profiling = atoi(e) != 0;
+    *out = ctx;
+    return RAYN_OK;
+}
+
+void rayn_hip_destroy(rayn_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    if (ctx->d_scene) (void)hipFree(ctx->d_scene);
+    if (ctx->d_evals) (void)hipFree(ctx->d_evals);
+    if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rayn_hip_last_error(const rayn_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rayn_hip_upload_world(rayn_ctx* ctx, const rayn_world_desc* world) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    if (!world) return fail(ctx, RAYN_ERR_INVALID_ARG, "null world");
+    if (world->n_hitables == 0 || world->n_hitables > RAYN_MAX_HITABLES || world->n_materials == 0 || world->n_materials > RAYN_MAX_MATERIALS ||
+        world->n_lights > RAYN_MAX_LIGHTS)
+        return fail(ctx, RAYN_ERR_INVALID_ARG, "world counts out of range");
+    ctx->world = *world;
+    ctx->have_world = true;
+    return RAYN_OK;
+}
+
+int rayn_hip_render_frame_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_samples_1d, const float* d_samples_2d,
+                                 const float* d_scramble, const float* d_fis_table, float* d_out_color, float* d_out_alpha,
+                                 float* d_out_background, float* d_out_normal, void* hip_stream) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    return render_device(ctx, p, d_samples_1d, d_samples_2d, d_scramble, d_fis_table, d_out_color, d_out_alpha, d_out_background, d_out_normal, s);
+}
+
+int rayn_hip_render_frame(rayn_ctx* ctx, const rayn_frame_params* p, const float* samples_1d, const float* samples_2d, const float* scramble,
+                          const float* fis_table, float* out_color, float* out_alpha, float* out_background, float* out_normal) {
+    int rc = validate(ctx, p);
+    if (rc) return rc;
+    if (!samples_1d || !samples_2d || !scramble || !fis_table || !out_color || !out_alpha || !out_background || !out_normal)
+        return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t spp = (size_t)p->samples * 4, npx = (size_t)p->width * p->height;
+    const size_t n1 = spp * rayn_sets_1d(p->max_bounces, p->volume_marches), n2 = spp * 2 * rayn_sets_2d(p->max_bounces, p->volume_marches);
+    float* d = nullptr;
+    const size_t total = n1 + n2 + npx + RAYN_FIS_TABLE_SIZE + npx * RAYN_FILM_FLOATS_PER_PIXEL;
+    if (hipMalloc((void**)&d, total * 4) != hipSuccess) return fail(ctx, RAYN_ERR_OOM, "hipMalloc of tables + film failed");
+    float *d1 = d, *d2 = d1 + n1, *dscr = d2 + n2, *dfis = dscr + npx, *dc = dfis + RAYN_FIS_TABLE_SIZE, *da = dc + 3 * npx, *db = da + npx, *dn = db + 3 * npx;
+    hipError_t e = hipSuccess;
+    auto up = [&](float* dst, const float* src, size_t n) { if (e == hipSuccess) e = hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice); };
+    up(d1, samples_1d, n1); up(d2, samples_2d, n2); up(dscr, scramble, npx); up(dfis, fis_table, RAYN_FIS_TABLE_SIZE);
+    up(dc, out_color, 3 * npx); up(da, out_alpha, npx); up(db, out_background, 3 * npx); up(dn, out_normal, 3 * npx); // keep un-owned pixels
+    if (e != hipSuccess) { hipFree(d); return fail(ctx, RAYN_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); }
+    rc = render_device(ctx, p, d1, d2, dscr, dfis, dc, da, db, dn, ctx->stream);
+    if (rc == RAYN_OK) {
+        auto down = [&](float* dst, const float* src, size_t n) { if (e == hipSuccess) e = hipMemcpy(dst, src, n * 4, hipMemcpyDeviceToHost); };
+        down(out_color, dc, 3 * npx); down(out_alpha, da, npx); down(out_background, db, 3 * npx); down(out_normal, dn, 3 * npx);
+        if (e != hipSuccess) rc = fail(ctx, RAYN_ERR_HIP, std::string("download: ") + hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
+int rayn_hip_get_stats(const rayn_ctx* ctx, rayn_stats* out) {
+    if (!ctx || !out) return RAYN_ERR_INVALID_ARG;
+    *out = ctx->stats;
+    return RAYN_OK;
+}
+
+/* profiling controls: per-kernel-class HIP-event timing (stats.ms_*) and SDF-evaluation counting
+ * (instrumented kernel variants; slower — for roofline accounting only). */
+int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    ctx->profiling = timing != 0;
+    ctx->counting = count_evals != 0;
+    return RAYN_OK;
+}
+int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t* extend_evals, uint64_t* shade_evals) {
+    if (!ctx || !extend_evals || !shade_evals) return RAYN_ERR_INVALID_ARG;
+    *extend_evals = ctx->evals_extend;
+    *shade_evals = ctx->evals_shade;
+    return RAYN_OK;
+}
+int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths) {
+    if (!ctx || paths < 4096) return RAYN_ERR_INVALID_ARG;
+    ctx->batch_paths = (size_t)paths;
+    return RAYN_OK;
+}
+
+/* ---- test probes: per-lane device primitives on caller data (HOST pointers) ---- */
+static int probe_common(rayn_ctx* ctx, const rayn_frame_params* p) {
+    int rc = validate(ctx, p);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    DScene hs;
+    rc = build_scene(ctx, ctx->world, *p, &hs);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(ctx->d_scene, &hs, sizeof hs, hipMemcpyHostToDevice));
+    return RAYN_OK;
+}
+int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t hitable_index, const float* pts, float* out, uint32_t n) {
+    int rc = probe_common(ctx, p);
+    if (rc) return rc;
+    float *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_in, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_in, pts, (size_t)n * 12, hipMemcpyHostToDevice));
+    launch_probe_dist(ctx->stream, ctx->d_scene, hitable_index, d_in, d_out, n);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_in); hipFree(d_out);
+    return RAYN_OK;
+}
+int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth, const float* org, const float* dir, float* out_t,
+                               uint32_t* out_obj, uint32_t n) {
+    int rc = probe_common(ctx, p);
+    if (rc) return rc;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; uint32_t* d_obj = nullptr;
+    HIPCHK(hipMalloc((void**)&d_o, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_d, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&d_t, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_obj, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_o, org, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    launch_probe_closest(ctx->stream, ctx->d_scene, depth, d_o, d_d, d_t, d_obj, n);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_obj, d_obj, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_obj);
+    return RAYN_OK;
+}
+int rayn_hip_probe_occluded(rayn_ctx* ctx, const rayn_frame_params* p, const float* start, const float* end, float* out, uint32_t n) {
+    int rc = probe_common(ctx, p);
+    if (rc) return rc;
+    float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_a, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_a, start, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, end, (size_t)n * 12, hipMemcpyHostToDevice));
+    launch_probe_occluded(ctx->stream, ctx->d_scene, d_a, d_b, d_out, n);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_a); hipFree(d_b); hipFree(d_out);
+    return RAYN_OK;
+}
+int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const float* b, float* out, uint32_t n) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_a, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_a, a, (size_t)n * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_probe_detmath(ctx->stream, op, d_a, d_b, d_out, n);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_a); hipFree(d_b); hipFree(d_out);
+    return RAYN_OK;
+}
+int rayn_hip_fma_policy(void) { return RAYN_FMA_POLICY; }
+size_t rayn_hip_sizeof(int which) {
+    switch (which) {
+    case 0: return sizeof(rayn_world_desc);
+    case 1: return sizeof(rayn_frame_params);
+    case 2: return sizeof(rayn_stats);
+    case 3: return sizeof(rayn_hitable);
+    case 4: return sizeof(rayn_material);
+    case 5: return sizeof(rayn_light);
+    case 6: return sizeof(rayn_camera);
+    default: return 0;
+    }
+}
+
+} // extern "C"

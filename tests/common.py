@@ -1,0 +1,23 @@
+"""Shared scene/config helpers for the tests (BASELINE.json configs scaled to oracle-sized cases)."""
+import numpy as np
+
+from rayn_amd import params as P
+from rayn_amd import setup as S
+
+
+def case(name, width, height, samples, bounces, **kw):
+    """Returns (world_desc, frame_params).  name: s0 (sphere SDF), s1 (MandelBox), s2 (MandelBox + volume)."""
+    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2}[name]((width, height))
+    return world.to_desc(cam), P.frame_params(width, height, samples, bounces, **kw)
+
+
+def film_l2(a, b):
+    """max over pixels of the per-pixel L2 distance over all 10 film floats (the north_star metric,
+    applied to every channel)."""
+    d2 = ((a["color"].astype(np.float64) - b["color"]) ** 2).sum(-1) + ((a["background"].astype(np.float64) - b["background"]) ** 2).sum(-1) \
+        + ((a["normal"].astype(np.float64) - b["normal"]) ** 2).sum(-1) + (a["alpha"].astype(np.float64) - b["alpha"]) ** 2
+    return float(np.sqrt(d2).max())
+
+
+def film_equal_bits(a, b):
+    return all(np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)) for k in ("color", "alpha", "background", "normal"))
