@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — Mpath-samples/s of the rayn hot path on MI355X (BASELINE.json metric).
+
+A "step" = one Film::render_frame_into of the workload (every tile, every sample, every bounce,
+film resolve included) with the sample tables, scramble, filter table and scene already resident in
+HBM.  N=1 renders BASELINE.json configs[1]: 1920x1080, 256 spp, 8 bounces, the reference's SDF fractal
+(a MandelBox — the reference has no Mandelbulb), volumes off.  N>1: the SAME frame is
+partitioned by tiles (round-robin) across ranks and gathered to rank 0 with one RCCL gather inside
+the timed region -> strong scaling.
+
+  python bench.py --gpus 1 --steps 2 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. "roofline" (dominant kernel
+class, HIP-event timed live) and "cpu_baseline" (the CPU oracle on a bounded tile sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_DIST = 404.0  # MandelBox::dist, 12 iterations x 33 + 8, fma = 2
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= f32-input MFMA peak)
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (scene, width, height, samples(=spp/4), bounces, description)
+    "c2": ("s1", 1920, 1080, 64, 8, "1920x1080, 256 spp, 8 bounces, MandelBox SDF (reference fractal), volumes off [BASELINE configs[1]]"),
+    "c3": ("s2", 1920, 1080, 256, 8, "1920x1080, 1024 spp, 8 bounces, MandelBox SDF + homogeneous volume [BASELINE configs[2]]"),
+    "c1": ("s0", 256, 256, 4, 4, "256x256, 16 spp, 4 bounces, single-sphere SDF [BASELINE configs[0]]"),
+    "small": ("s1", 480, 270, 4, 3, "480x270, 16 spp, 3 bounces, MandelBox (quick check)"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import rayn_amd
+    from rayn_amd import setup as S
+    from rayn_amd.distributed import FilmGather
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    scene, W, H, samples, bounces, desc = WORKLOADS[args.workload]
+    spp = 4 * samples
+    cam, wld = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2}[scene]((W, H))
+    wd = wld.to_desc(cam)
+    p = rayn_amd.frame_params(W, H, samples, bounces, tile_first=rank, tile_step=world)
+    tabs = rayn_amd.build_tables(spp, bounces, p.volume_marches, p.frame, W, H)
+    ctx = rayn_amd.Context(local_rank)
+    ctx.upload_world(wd)
+    d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
+    film = rayn_amd.film.alloc_device_film(W, H, device)
+    gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device) if world > 1 else None
+
+    def step():
+        ctx.render_device(p, d_tabs, film)
+        if gather is not None:
+            return gather.gather(film)
+        return film
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    paths_per_step = W * H * spp
+    value = paths_per_step * args.steps / dt / 1e6
+    stats = ctx.stats()
+
+    roofline = None
+    roofline_hbm = None
+    if not args.no_roofline:
+        # (1) per-kernel-class HIP-event timing with the production kernels, (2) SDF-evaluation counts with
+        # the instrumented variants.  Both outside the timed region.
+        ctx.set_profiling(True, False)
+        ctx.render_device(p, d_tabs, film)
+        torch.cuda.synchronize()
+        st = ctx.stats()
+        ctx.set_profiling(False, True)
+        ctx.render_device(p, d_tabs, film)
+        torch.cuda.synchronize()
+        ev_extend, ev_shade = ctx.eval_counts()
+        ctx.set_profiling(False, False)
+        classes = {"extend": (st["ms_extend"], ev_extend, st["launches_extend"]), "shade": (st["ms_shade"], ev_shade, st["launches_shade"])}
+        dom = max(classes, key=lambda k: classes[k][0])
+        ms, evals, launches = classes[dom]
+        achieved = FLOP_PER_DIST * evals / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"kernel": f"k_{dom}", "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
+                    "flop_per_launch": FLOP_PER_DIST * evals / max(launches, 1), "dist_evals": evals,
+                    "note": "march kernels are FP32-VALU bound (SURVEY.md F6): achieved = 404 flop x SDF evals / kernel time; "
+                            "peak = MI355X FP32 vector peak (= dense f32-input MFMA peak)"}
+        qms = st["ms_raygen"] + st["ms_bin"] + st["ms_compact"] + st["ms_resolve"]
+        qbytes = st["queue_bytes"] + 68 * st["paths"] + 40 * W * H / world + 24 * st["paths"]  # scatter/compact + ray-gen + film + resolve reads
+        ach = qbytes / (qms * 1e-3) / 1e9 if qms > 0 else 0.0
+        roofline_hbm = {"kernels": "k_raygen+k_scan_tile+k_tile_prefix+k_bin_scatter+k_compact_scatter+k_resolve", "bound": "hbm",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "ms": round(qms, 3)}
+        kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_compact", "ms_resolve", "ms_total")}
+    else:
+        kernel_ms = None
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from oracle import oracle_py as O
+        threads = os.cpu_count() or 1
+        n_tiles = rayn_amd._lib.lib().rayn_tile_count(W, H, p.tile_w, p.tile_h)
+        p0 = rayn_amd.frame_params(W, H, samples, bounces)
+        # calibrate on one spread tile per thread, then size the sample for ~cpu_seconds
+        def run(k):
+            sub = np.unique(np.linspace(0, n_tiles - 1, num=min(k, n_tiles)).astype(np.uint32))
+            t = time.perf_counter()
+            _, ctr = O.render(wd, p0, tabs, threads=threads, tile_subset=sub)
+            return time.perf_counter() - t, ctr.paths, len(sub)
+        t_cal, paths_cal, k_cal = run(threads)
+        k = int(min(n_tiles, max(threads, k_cal * args.cpu_seconds / max(t_cal, 1e-3))))
+        t_cpu, paths_cpu, k_used = run(k)
+        cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
+                        "sample": f"{k_used} of {n_tiles} tiles (evenly spread, {paths_cpu} paths) of the same workload, C++ oracle "
+                                  f"(restatement of rayn's CPU path; rayn itself cannot be built here), {t_cpu:.1f} s"}
+
+    if rank == 0:
+        out = {
+            "metric": "Mpath-samples/sec", "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "paths_per_step": paths_per_step, "tile": [p.tile_w, p.tile_h], "fma_policy": "unfused (reference default build)",
+                       "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one RCCL gather to rank 0 per frame" if world > 1 else "")},
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "kernel_ms": kernel_ms,
+            "segments_per_step": stats["segments"] * world if world > 1 else stats["segments"],
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""Host table builders: product vs oracle bit-for-bit, plus known-answer
+checks computed independently in Python big-integer arithmetic."""
+from fractions import Fraction
+from math import isqrt
+
+import numpy as np
+
+import rayn_amd
+
+
+def test_product_tables_equal_oracle(oracle):
+    for (spp, B, VM, frame, w, h) in [(16, 3, 2, 1, 64, 48), (8, 8, 2, 7, 33, 17), (4, 2, 3, 1, 16, 16)]:
+        a = rayn_amd.build_tables(spp, B, VM, frame, w, h)
+        b = oracle.build_tables(spp, B, VM, frame, w, h)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_set_counts():
+    L = rayn_amd._lib.lib()
+    # sets_1d = 1 + (B+1)(3+VM), sets_2d = 2 + (B+1)(12+8VM)   src/film.rs:431-432, src/integrator.rs:39-45
+    assert L.rayn_sets_1d(3, 2) == 1 + 4 * 5 and L.rayn_sets_2d(3, 2) == 2 + 4 * 28
+    assert L.rayn_sets_1d(8, 2) == 46 and L.rayn_sets_2d(8, 2) == 254
+
+
+def _golden_inverse(bits=200):
+    # 1/phi = (sqrt(5)-1)/2 to 'bits' bits
+    s = isqrt(5 << (2 * bits))
+    return Fraction(s - (1 << bits), 1 << (bits + 1))
+
+
+def test_rd_1d_known_answers():
+    spp, B, VM, frame = 8, 1, 2, 3
+    s1, _, _, _ = rayn_amd.build_tables(spp, B, VM, frame, 4, 4)
+    a = _golden_inverse()
+    for set_i in (0, 2):
+        for k in (0, 5):
+            idx = ((frame + set_i) << 32) + 1 + k
+            x = (Fraction(1, 2) + a * idx) % 1
+            want = np.float32(int(x * (1 << 24)) / float(1 << 24))
+            assert s1[spp * set_i + k] == want
+    assert np.all((s1 >= 0) & (s1 < 1))
+
+
+def test_rd_2d_is_low_discrepancy():
+    spp = 256
+    _, s2, _, _ = rayn_amd.build_tables(spp, 0, 2, 1, 4, 4)
+    pts = s2[: 2 * spp].reshape(-1, 2)
+    hist, _, _ = np.histogram2d(pts[:, 0], pts[:, 1], bins=8, range=[[0, 1], [0, 1]])
+    assert hist.min() >= 2 and hist.max() <= 7  # 4 expected per cell
+
+
+def test_scramble_is_pcg64mcg_first_f32():
+    _, _, scr, _ = rayn_amd.build_tables(4, 0, 2, 1, 8, 4)
+
+    def ref(seed):
+        M64 = (1 << 64) - 1
+        st, w = seed, []
+        for _ in range(4):
+            st = (st * 6364136223846793005 + 11634580027462260723) & M64
+            xs = (((st >> 18) ^ st) >> 27) & 0xFFFFFFFF
+            rot = st >> 59
+            w.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        state = (w[0] | (w[1] << 32) | (w[2] << 64) | (w[3] << 96)) | 1
+        state = (state * 0x2360ED051FC65DA44385DF649FCCF645) & ((1 << 128) - 1)
+        rot = state >> 122
+        xsl = ((state >> 64) ^ state) & M64
+        out = ((xsl >> rot) | (xsl << ((64 - rot) & 63))) & M64
+        return np.float32(((out & 0xFFFFFFFF) >> 8) / float(1 << 24))
+
+    for pix in (0, 1, 7, 31):
+        assert scr[pix] == ref(pix)
+    assert len(np.unique(scr)) == scr.size
+
+
+def test_fis_table_shape():
+    _, _, _, fis = rayn_amd.build_tables(4, 0, 2, 1, 4, 4)
+    assert fis.shape == (512,) and fis[0] == 0.0
+    assert np.all(np.diff(fis) >= 0)
+    assert fis[-1] <= 1.5 and fis[256] > 0.2 and fis[256] < 0.45  # Blackman-Harris r=1.5 is concentrated near 0
