@@ -128,14 +128,16 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
         const f3 offset = p;
         float dr = 1.0f;
         const float l = h.box_l, nl = -h.box_l, s = h.scale;
+        // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
+        // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
         for (uint32_t i = 0; i < h.iterations; i++) {
             // box_fold: clamped(-l, l).mul_add(2, -p)
-            p.x = muladd(fmins(fmaxs(p.x, nl), l), 2.0f, -p.x);
-            p.y = muladd(fmins(fmaxs(p.y, nl), l), 2.0f, -p.y);
-            p.z = muladd(fmins(fmaxs(p.z, nl), l), 2.0f, -p.z);
+            p.x = muladd(__builtin_amdgcn_fmed3f(p.x, nl, l), 2.0f, -p.x);
+            p.y = muladd(__builtin_amdgcn_fmed3f(p.y, nl, l), 2.0f, -p.y);
+            p.z = muladd(__builtin_amdgcn_fmed3f(p.z, nl, l), 2.0f, -p.z);
             // sphere_fold
             float r2 = mag_sq(p);
-            float m = fmaxs(1.0f, h.fixed_rad_sq / fmaxs(h.min_rad_sq, r2));
+            float m = __builtin_fmaxf(1.0f, h.fixed_rad_sq / __builtin_fmaxf(h.min_rad_sq, r2));
             p.x *= m; p.y *= m; p.z *= m;
             dr *= m;
             p.x = muladd(p.x, s, offset.x);

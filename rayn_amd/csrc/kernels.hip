@@ -13,6 +13,8 @@
 // ballots (mbcnt) + a block scan — never atomics-append.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_core.h"
 #include "kernels.h"
 
@@ -69,32 +71,106 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
 // Writes t + object into the pool, the object per entry, and the per-group object histogram that
 // the bin scan consumes (wave ballot, no atomics).
 // ------------------------------------------------------------------------------------------------
+// Persistent waves: march lengths vary 1..257 per ray, so a thread-per-ray launch idles most lanes.
+// Here every lane owns a small state machine; a lane whose ray is finished immediately takes the
+// next queue entry (wave-local chunk of 256 entries, refilled with ONE atomic per chunk), so every
+// loop iteration evaluates the SDF on (almost) all 64 lanes.  Results are written by entry/pool
+// index, so the fetch order never influences the output.
+constexpr uint32_t CHUNK = 256;
+
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, uint32_t depth, const uint32_t* __restrict__ q,
                                                  uint32_t n_entries, Pool pool, uint8_t* __restrict__ ent_obj,
-                                                 uint8_t* __restrict__ grp_cnt, unsigned long long* __restrict__ evals_out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_entries) return; // n_entries is a multiple of 64: whole waves exit together
+                                                 uint32_t* __restrict__ head, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
-    const uint32_t P = q[i];
-    uint32_t obj = OBJ_NONE;
-    uint32_t evals = 0;
-    if (P != INVALID) {
-        f3 o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
-        f3 d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
-        Thr th = make_thr(sc, depth);
-        float t;
-        closest_hit<COUNT>(sc, o, d, th, &t, &obj, evals);
-        pool.hit_t[P] = t;
-        pool.hit_obj[P] = (uint8_t)obj;
+    const uint32_t lane = lane_id();
+    const Thr th = make_thr(sc, depth);
+    const uint32_t nh = sc.n_hitables;
+    const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
+    uint32_t cur = 0, end = 0; // wave-uniform chunk window
+    bool exhausted = false;
+    // per-lane ray state
+    bool has = false, first = false, nan = false;
+    uint32_t ent = 0, P = 0, k = 0, id = OBJ_NONE, m = 0, evals = 0;
+    f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
+    float closest = 0.0f, t = 0.0f;
+    // fold over the hitables (src/hitable.rs:177-198) up to the next TracedSDF; finish the ray at the end
+    auto advance = [&]() {
+        while (k < nh) {
+            const DHitable& hh = sc.h[k];
+            if (hh.kind != RAYN_HITABLE_SPHERE) { first = true; return; }
+            float ts = sphere_hit(hh, o, d, closest);
+            if (ts < closest) { closest = ts; id = k; }
+            k++;
+        }
+        pool.hit_t[P] = closest;
+        pool.hit_obj[P] = (uint8_t)id;
+        ent_obj[ent] = (uint8_t)id;
+        has = false;
+    };
+    for (;;) {
+        for (;;) { // refill idle lanes until every lane is inside a march (or the queue is empty)
+            const uint64_t need = __ballot(!has);
+            if (need == 0) break;
+            if (cur == end) {
+                if (exhausted) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n_entries) { exhausted = true; break; }
+                cur = base;
+                end = min(base + CHUNK, n_entries);
+            }
+            const uint32_t rank = mbcnt(need), avail = end - cur;
+            if (!has && rank < avail) {
+                ent = cur + rank;
+                P = q[ent];
+                if (P == INVALID) ent_obj[ent] = (uint8_t)OBJ_NONE;
+                else {
+                    o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
+                    d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
+                    closest = sc.t_max; id = OBJ_NONE; k = 0; has = true;
+                    advance();
+                }
+            }
+            cur += min((uint32_t)__popcll(need), avail);
+        }
+        const uint64_t act = __ballot(has);
+        if (act == 0) break;
+        // all lanes of this step evaluate the same SDF object (scenes normally hold exactly one)
+        const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)__builtin_ctzll(act));
+        const DHitable& h = sc.h[ku];
+        if (has && k == ku) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
+            const f3 p = first ? o : muladd3(d, t, o);
+            const float dist = sdf_dist<COUNT>(h, p, evals);
+            bool done;
+            if (first) { t = dist; nan = dist != dist; first = false; m = 0; done = sc.max_marches == 0; }
+            else {
+                const bool hit = __builtin_fabsf(dist) < fmaxs(c0, c1 * thr_at(th, t));
+                const bool gt = t > closest;
+                done = hit || nan || gt;
+                if (!done) { t = t + dist; m++; done = m == sc.max_marches; }
+            }
+            if (done) {
+                if (t < closest) { closest = t; id = k; }
+                k++;
+                advance();
+            }
+        }
     }
-    ent_obj[i] = (uint8_t)obj;
-    const uint32_t g = i >> 6, lane = lane_id();
-    for (uint32_t c = 0; c < sc.n_hitables; c++) {
+    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+}
+
+// per-group object histogram of the extend results (input of the bin scan)
+__global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8_t* __restrict__ ent_obj, uint32_t n_entries,
+                                                     uint8_t* __restrict__ grp_cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    const uint32_t obj = ent_obj[i], g = i >> 6, lane = lane_id();
+    for (uint32_t c = 0; c < nclass; c++) {
         uint64_t m = __ballot(obj == c);
         if (lane == c) grp_cnt[g * SCAN_NC_BIN + c] = (uint8_t)__popcll(m);
     }
-    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,15 +602,19 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
 
 // ---- launch wrappers (declared in kernels.h) -----------------------------------------------------
 static inline dim3 grid_for(uint32_t n, uint32_t block) { return dim3((n + block - 1) / block); }
+constexpr uint32_t PERSISTENT_BLOCKS = 256 * 8; // 256 CUs x 8 blocks of 4 waves = 32 waves per CU
 
 void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
                    Pool pool, uint32_t* q, uint32_t n_pool) {
     hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool);
 }
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, unsigned long long* evals) {
-    if (count) hipLaunchKernelGGL(k_extend<true>, grid_for(n_entries, 256), dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, grp_cnt, evals);
-    else hipLaunchKernelGGL(k_extend<false>, grid_for(n_entries, 256), dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, grp_cnt, evals);
+                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, uint32_t* head, unsigned long long* evals) {
+    (void)hipMemsetAsync(head, 0, 4, s);
+    const dim3 grid(std::min<uint32_t>(PERSISTENT_BLOCKS, (n_entries + 255) / 256));
+    if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, evals);
+    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, evals);
+    hipLaunchKernelGGL(k_group_hist, grid_for(n_entries, 256), dim3(256), 0, s, nclass, ent_obj, n_entries, grp_cnt);
 }
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
                       const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,

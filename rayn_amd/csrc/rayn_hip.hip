@@ -244,7 +244,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     acc(BG, 1); acc(BG, 4); acc(BG, 4);                                                            // bgrp_*
     acc(max_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                           // tiles, pgrp_tile
     for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
-    acc(2, 4);
+    acc(2, 4); acc(8, 4);
     if (need > ctx->arena.cap) {
         if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
         ctx->arena.base = nullptr; ctx->arena.cap = 0;
@@ -271,6 +271,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     uint32_t* tgbB = A.take<uint32_t>(max_tiles); uint32_t* tgcB = A.take<uint32_t>(max_tiles);
     uint32_t* tile_total = A.take<uint32_t>(max_tiles); uint32_t* tile_valid = A.take<uint32_t>(max_tiles); uint32_t* tile_out_base = A.take<uint32_t>(max_tiles);
     uint32_t* d_totals = A.take<uint32_t>(2);
+    uint32_t* d_counters = A.take<uint32_t>(8);
     if (A.off > A.cap) return fail(ctx, RAYN_ERR_OOM, "internal: arena under-sized");
 
     hipEvent_t ev_a = get_event(ctx), ev_b = get_event(ctx);
@@ -306,7 +307,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         uint32_t n_entries = (uint32_t)n_pool;
         uint32_t* qcur = q; uint32_t* qnext = qn;
         for (uint32_t depth = 0; n_entries > 0; depth++) {
-            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, ctx->d_evals); }
+            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, d_counters, ctx->d_evals); }
             ctx->stats.launches_extend++;
             {
                 Timed t(ctx, stream, PC_BIN);
