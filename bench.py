@@ -121,9 +121,10 @@ def main():
         ctx.set_profiling(False, True)
         ctx.render_device(p, d_tabs, film)
         torch.cuda.synchronize()
-        ev_extend, ev_shade = ctx.eval_counts()
+        ev = ctx.eval_counts()
         ctx.set_profiling(False, False)
-        classes = {"extend": (st["ms_extend"], ev_extend, st["launches_extend"]), "shade": (st["ms_shade"], ev_shade, st["launches_shade"])}
+        classes = {"extend": (st["ms_extend"], ev["extend"], st["launches_extend"]), "shadow": (st["ms_shadow"], ev["shadow"], st["launches_shade"]),
+                   "shade_setup": (st["ms_shade"], ev["shade_setup"], st["launches_shade"])}
         dom = max(classes, key=lambda k: classes[k][0])
         ms, evals, launches = classes[dom]
         achieved = FLOP_PER_DIST * evals / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -131,15 +132,17 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
                     "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                     "flop_per_launch": FLOP_PER_DIST * evals / max(launches, 1), "dist_evals": evals,
+                    "all_march_kernels": {k: {"ms": round(v[0], 3), "dist_evals": v[1],
+                                              "tflops": round(FLOP_PER_DIST * v[1] / max(v[0], 1e-9) / 1e9, 3)} for k, v in classes.items()},
                     "note": "march kernels are FP32-VALU bound (SURVEY.md F6): achieved = 404 flop x SDF evals / kernel time; "
                             "peak = MI355X FP32 vector peak (= dense f32-input MFMA peak)"}
-        qms = st["ms_raygen"] + st["ms_bin"] + st["ms_compact"] + st["ms_resolve"]
+        qms = st["ms_raygen"] + st["ms_bin"] + st["ms_compact"] + st["ms_resolve"] + st["ms_finish"]
         qbytes = st["queue_bytes"] + 68 * st["paths"] + 40 * W * H / world + 24 * st["paths"]  # scatter/compact + ray-gen + film + resolve reads
         ach = qbytes / (qms * 1e-3) / 1e9 if qms > 0 else 0.0
-        roofline_hbm = {"kernels": "k_raygen+k_scan_tile+k_tile_prefix+k_bin_scatter+k_compact_scatter+k_resolve", "bound": "hbm",
+        roofline_hbm = {"kernels": "k_raygen+k_scan_tile+k_tile_prefix+k_bin_scatter+k_shade_finish+k_compact_scatter+k_resolve", "bound": "hbm",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "ms": round(qms, 3)}
-        kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_compact", "ms_resolve", "ms_total")}
+        kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_shadow", "ms_finish", "ms_compact", "ms_resolve", "ms_total")}
     else:
         kernel_ms = None
 

@@ -149,9 +149,10 @@ typedef struct {
     uint64_t tiles;
     uint64_t batches;
     double ms_total;         /* HIP-event time of the whole render on the ctx stream */
-    double ms_raygen, ms_extend, ms_bin, ms_shade, ms_compact, ms_resolve;
+    double ms_raygen, ms_extend, ms_bin, ms_shade, ms_compact, ms_resolve; /* ms_shade = k_shade_setup */
     uint64_t launches_extend, launches_shade;
     uint64_t queue_bytes;    /* algorithmic HBM bytes moved by the queue kernels */
+    double ms_shadow, ms_finish; /* k_shadow, k_shade_finish */
 } rayn_stats;
 
 typedef struct rayn_ctx rayn_ctx;
@@ -210,7 +211,8 @@ uint32_t rayn_tile_count(uint32_t width, uint32_t height, uint32_t tile_w, uint3
 /* timing: bracket every kernel launch with HIP events and fill rayn_stats.ms_*; count_evals: run
  * the instrumented kernel variants that count SDF distance evaluations (roofline accounting). */
 int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals);
-int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t* extend_evals, uint64_t* shade_evals);
+/* out[0] k_extend (closest-hit marches), out[1] k_shade_setup (normal estimation), out[2] k_shadow (NEE visibility) */
+int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
 /* path-pool capacity per batch of tiles (default 2^25 paths ~ 3.3 GB of HBM). */
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
 /* 0: a*b+c unfused (reference default build), 1: fused (see include/rayn_detmath.h). */

@@ -60,7 +60,7 @@ def lib():
         L.rayn_tile_count.restype = C.c_uint32
         L.rayn_tile_count.argtypes = [C.c_uint32] * 4
         L.rayn_hip_set_profiling.argtypes = [vp, C.c_int, C.c_int]
-        L.rayn_hip_get_eval_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.rayn_hip_get_eval_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rayn_hip_set_batch_paths.argtypes = [vp, C.c_uint64]
         L.rayn_hip_sizeof.restype = C.c_size_t
         L.rayn_hip_sizeof.argtypes = [C.c_int]

@@ -21,6 +21,30 @@ struct Pool {
     uint8_t* obj0;
 };
 
+// per-slot NEE records + the shadow-job list (see k_shade_setup)
+struct Nee {
+    float* x;      // [ns][3][cap] unoccluded contribution (Le*f)*transmission
+    float* pdf;    // [ns][cap]
+    float* aux;    // [ns-4][cap] volume samples: exp(-rho_t * sample distance)
+    uint8_t* vis;  // [ns][cap]   HitableStore::test_occluded: 0 occluded, 1 visible, 2 SDF march pending
+    float* T;      // [cap]       volume transmission of the segment
+    float* nthr;   // [3][cap]    throughput of the spawned ray
+    uint8_t* flags; // [cap]      bit0 alive, bit1 surface NEE, bit2 volume NEE
+    uint32_t cap;
+    uint32_t* job_ref; // [jobcap] dense list of pending [sample*cap + slot] indices (k_shadow_list)
+    float* job_geo;    // [6][jobcap] pending shadow segments: start xyz, end xyz at [sample*cap + slot]
+    uint32_t jobcap;
+};
+
+// the host brackets the three shading kernels with its profiling events through these hooks
+struct ShadeHooks {
+    void* user;
+    void (*before_fn)(void*, int);
+    void (*after_fn)(void*, int);
+    void before(int i) const { if (before_fn) before_fn(user, i); }
+    void after(int i) const { if (after_fn) after_fn(user, i); }
+};
+
 struct Tables { const float* __restrict__ s1d; const float* __restrict__ s2d; const float* __restrict__ fis; };
 
 void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
@@ -35,7 +59,8 @@ void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_to
 void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
                         const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq);
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
-                  uint32_t n_slots, Pool pool, uint8_t* alive, uint8_t* bgrp_cnt, unsigned long long* evals);
+                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
+                  unsigned long long* evals, ShadeHooks hooks);
 void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
                             const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn);
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,

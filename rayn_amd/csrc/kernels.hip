@@ -328,17 +328,26 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// a15-a24: shading info + PathTracingIntegrator::integrate (src/integrator.rs:47-204) for one packet
-// lane per thread.  Slots 4k..4k+3 of the binned queue are one reference packet; the only cross-lane
-// data are the light indices each lane draws from ITS OWN 1-D sample (src/integrator.rs:76-82,
-// 100-110), exchanged with wave shuffles.  Padding lanes use sample 0 / scramble 0
-// (Ray::new_invalid, src/ray.rs:54-66) and still contribute their pick.
+// a15-a24: shading = three kernels per depth.
+//   k_shade_setup  (one thread per binned slot): get_shading_info, emission, the light samples of
+//                  NEE (surface 4x, volume 4xVM), BSDF scatter, roulette, AOVs, new ray.  For every
+//                  NEE sample it stores the UNOCCLUDED contribution x = (Le*f)*transmission and its
+//                  pdf, resolves the analytic-sphere part of HitableStore::test_occluded inline and
+//                  appends a shadow job when an SDF march is still needed.
+//   k_shadow       (persistent waves over the job list): TracedSDF::occluded, src/sdf.rs:25-57.
+//   k_shade_finish (one thread per slot): radiance += ((x*occluded)/pdf) * throughput * ... in the
+//                  reference's order (src/integrator.rs:91-92,128-129), then publishes the new throughput.
+// Slots 4k..4k+3 of the binned queue are one reference packet; the only cross-lane data are the light
+// indices each lane draws from ITS OWN 1-D sample (src/integrator.rs:76-82,100-110), exchanged with
+// wave shuffles.  Padding lanes use sample 0 / scramble 0 (Ray::new_invalid, src/ray.rs:54-66).
 // ------------------------------------------------------------------------------------------------
+RD bool all_zero(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
+
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
-                                                uint32_t depth, const uint32_t* __restrict__ bq, uint32_t n_slots, Pool pool,
-                                                uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt,
-                                                unsigned long long* __restrict__ evals_out) {
+__global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
+                                                      uint32_t depth, const uint32_t* __restrict__ bq, uint32_t n_slots, Pool pool, Nee nee,
+                                                      uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt,
+                                                      unsigned long long* __restrict__ evals_out) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_slots) return; // multiple of 64
     const DScene& sc = *scp;
@@ -349,8 +358,8 @@ __global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, T
     uint32_t sample = 0, pix = 0;
     float scr = 0.0f;
     if (valid) { sample = pool.samp[P]; pix = pool.pix[P]; scr = scramble[pix]; }
-    const uint32_t set1 = 1 + depth * n1;      // 1-D set of samples_1d[0] at this depth, src/film.rs:568-574
-    const uint32_t set2 = 2 + depth * n2h;     // 2-D set of samples_2d[0..1], src/film.rs:579-589
+    const uint32_t set1 = 1 + depth * n1;  // 1-D set of samples_1d[0] at this depth, src/film.rs:568-574
+    const uint32_t set2 = 2 + depth * n2h; // 2-D set of samples_2d[0..1], src/film.rs:579-589
     // light picks: each lane draws an index from ITS 1-D sample; the packet's four picks are packed
     // 4 bits each (n_lights <= 16) so the rolled loops below need no register arrays.
     uint32_t surf_picks = 0;
@@ -366,22 +375,37 @@ __global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, T
             else vol_picks |= (unsigned long long)packed << (16 * (k - 1));
         }
     }
+    const uint32_t cap = nee.cap;
+    const bool scene_has_sdf = sc.n_sdf > 0;
     bool is_alive = false;
-    uint32_t evals = 0;
+    uint32_t evals = 0, flags = 0;
+    // shadow jobs live IN PLACE: vis[s][slot] = 2 marks "SDF march pending" and the segment is parked at
+    // job_geo[..][s*cap + slot]; k_shadow scans all (sample, slot) pairs.  (A compacted job list would need
+    // one atomic per wave per sample on a single counter - that alone cost 0.5 s per frame.)
+    auto park_job = [&](uint32_t s, f3 a, f3 b) {
+        const uint32_t idx = s * cap + j, jc = nee.jobcap;
+        nee.job_geo[idx] = a.x; nee.job_geo[jc + idx] = a.y; nee.job_geo[2 * jc + idx] = a.z;
+        nee.job_geo[3 * jc + idx] = b.x; nee.job_geo[4 * jc + idx] = b.y; nee.job_geo[5 * jc + idx] = b.z;
+    };
+    // analytic spheres of test_occluded (every factor is exactly 0 or 1 -> order independent)
+    auto spheres_visible = [&](f3 a, f3 b) {
+        for (uint32_t k = 0; k < sc.n_hitables; k++)
+            if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], a, b) == 0.0f) return false;
+        return true;
+    };
+    f3 o = f3{0, 0, 0}, d = f3{0, 0, 0}, rad = f3{0, 0, 0}, thr = f3{0, 0, 0}, point = f3{0, 0, 0}, normal = f3{0, 0, 1};
+    float t = 0.0f, offset_by = 0.0f, vol_T = 1.0f;
+    uint32_t obj = 0;
+    bool receives = false;
     if (valid) {
-        f3 o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
-        f3 d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
-        f3 rad = f3{pool.lr[P], pool.lg[P], pool.lb[P]};
-        f3 thr = f3{pool.tr[P], pool.tg[P], pool.tb[P]};
-        const float t = pool.hit_t[P];
-        // object of this slot: recover from the hit stage
-        const uint32_t obj = pool.hit_obj[P];
+        o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
+        d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
+        rad = f3{pool.lr[P], pool.lg[P], pool.lb[P]};
+        thr = f3{pool.tr[P], pool.tg[P], pool.tb[P]};
+        t = pool.hit_t[P];
+        obj = pool.hit_obj[P];
         const DHitable& h = sc.h[obj];
-        const DMaterial& mat = sc.m[h.material];
-        // get_shading_info
-        f3 point = muladd3(d, t, o); // WHit::point -> Ray::point_at
-        f3 normal;
-        float offset_by;
+        point = muladd3(d, t, o); // WHit::point -> Ray::point_at
         if (h.kind == RAYN_HITABLE_SPHERE) { // src/sphere.rs:73-86
             normal = normalized(point - h.center);
             offset_by = 0.0f;
@@ -391,14 +415,21 @@ __global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, T
             normal = sdf_normal<COUNT>(h, point, hps, evals);
             offset_by = hps;
         }
-        const Basis basis = orthonormal_basis(normal);
-        const f3 wo = -d;
-        const float vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
-        rad = rad + bsdf_le(mat, wo) * thr * vol_T;
-        const bool receives = mat.receives_light != 0;
-        if (receives && nl > 0) {
-            const float corr = (float)nl / 4.0f;
-            for (uint32_t i = 0; i < 4; i++) { // surface_sample_one_light, src/integrator.rs:207-240
+        vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
+        receives = sc.m[h.material].receives_light != 0;
+        rad = rad + bsdf_le(sc.m[h.material], -d) * thr * vol_T;
+        pool.lr[P] = rad.x; pool.lg[P] = rad.y; pool.lb[P] = rad.z;
+        nee.T[j] = vol_T;
+    }
+    const DMaterial& mat = sc.m[sc.h[obj].material];
+    const f3 wo = -d;
+    // ---- surface NEE, surface_sample_one_light src/integrator.rs:207-240
+    const bool do_surf = valid && receives && nl > 0;
+    {
+        if (do_surf) flags |= 2u;
+        for (uint32_t i = 0; i < 4; i++) {
+            if (!do_surf) nee.vis[i * cap + j] = 1; // nothing pending for this (sample, slot)
+            else {
                 const DLight& L = sc.l[(surf_picks >> (4 * i)) & 15u];
                 float u0 = sample_2d(tab, spp, 0, sample, scr, set2 + i), u1 = sample_2d(tab, spp, 1, sample, scr, set2 + i);
                 f3 end_point; float pdf;
@@ -407,18 +438,31 @@ __global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, T
                 float dist = mag(wi);
                 wi = wi / dist;
                 f3 occlude_point = point + normal * signum(dot(normal, wi)) * offset_by;
-                float occ = test_occluded<COUNT>(sc, occlude_point, end_point, evals);
                 f3 f = bsdf_f(mat, wo, wi, normal) * fmaxs(dot(normal, wi), 0.0f);
                 float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dist) : 1.0f;
-                f3 li = L.emission * f * tr * occ / pdf;
-                rad = rad + li * thr * corr * vol_T;
+                f3 x = L.emission * f * tr;
+                nee.x[(i * 3 + 0) * cap + j] = x.x; nee.x[(i * 3 + 1) * cap + j] = x.y; nee.x[(i * 3 + 2) * cap + j] = x.z;
+                nee.pdf[i * cap + j] = pdf;
+                uint8_t vis = 1;
+                // x == 0 (light below the horizon): (x*occluded)/pdf is the same zero for occluded 0 or 1 -> no test needed
+                if (!all_zero(x)) {
+                    if (!spheres_visible(occlude_point, end_point)) vis = 0;
+                    else if (scene_has_sdf) { vis = 2; park_job(i, occlude_point, end_point); }
+                }
+                nee.vis[i * cap + j] = vis;
             }
         }
-        if (sc.has_scatter && nl > 0) { // src/integrator.rs:96-132
-            const float corr = (float)nl / 4.0f / (float)VM;
-            const float vsample = sample_1d(tab, spp, sample, scr, set1 + 1); // samples_1d[1] for every march
-            for (uint32_t march = 0; march < VM; march++) {
-                for (uint32_t i = 0; i < 4; i++) { // volume_sample_one_light :242-281
+    }
+    // ---- volume NEE, volume_sample_one_light src/integrator.rs:242-281 (runs for every segment)
+    const bool do_vol = valid && sc.has_scatter && nl > 0;
+    if (sc.has_scatter) {
+        if (do_vol) flags |= 4u;
+        const float vsample = sample_1d(tab, spp, sample, scr, set1 + 1); // samples_1d[1] for every march
+        for (uint32_t march = 0; march < VM; march++) {
+            for (uint32_t i = 0; i < 4; i++) {
+                const uint32_t s = 4 + 4 * march + i;
+                if (!do_vol) nee.vis[s * cap + j] = 1;
+                else {
                     const DLight& L = sc.l[(uint32_t)(vol_picks >> (16 * march + 4 * i)) & 15u];
                     const uint32_t set = set2 + 4 + 4 * march + i; // comps 8+8*march+2i, +1
                     float u0 = sample_2d(tab, spp, 0, sample, scr, set), u1 = sample_2d(tab, spp, 1, sample, scr, set);
@@ -428,17 +472,25 @@ __global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, T
                     f3 end_point; float lpdf;
                     light_sample(L, u0, u1, sp, &end_point, &lpdf);
                     float dl = mag(end_point - sp);
-                    float occ = test_occluded<COUNT>(sc, sp, end_point, evals);
                     float f = 1.0f / (4.0f * PI_F);
                     float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dl) : 1.0f;
-                    f3 li = L.emission * f * tr * occ / (vpdf * lpdf);
-                    float tr2 = sc.has_extinct ? dm_expf(-sc.rho_t * vdist) : 1.0f;
-                    rad = rad + li * thr * corr * sc.rho_s * tr2;
+                    f3 x = L.emission * f * tr;
+                    nee.x[(s * 3 + 0) * cap + j] = x.x; nee.x[(s * 3 + 1) * cap + j] = x.y; nee.x[(s * 3 + 2) * cap + j] = x.z;
+                    nee.pdf[s * cap + j] = vpdf * lpdf;
+                    nee.aux[(s - 4) * cap + j] = sc.has_extinct ? dm_expf(-sc.rho_t * vdist) : 1.0f;
+                    uint8_t vis = 1;
+                    if (!spheres_visible(sp, end_point)) vis = 0;
+                    else if (scene_has_sdf) { vis = 2; park_job(s, sp, end_point); }
+                    nee.vis[s * cap + j] = vis;
                 }
             }
         }
+    }
+    // ---- BSDF sample, roulette, AOVs, termination (src/integrator.rs:134-203)
+    if (valid) {
         uint32_t key = (depth << 26) | j;
         if (receives) {
+            const Basis basis = orthonormal_basis(normal);
             const uint32_t bset = set2 + 4 + 4 * VM; // comps 8+8*VM .. +3
             float s3 = sample_1d(tab, spp, sample, scr, set1 + 3), s4 = sample_1d(tab, spp, sample, scr, set1 + 4);
             Scatter se = bsdf_scatter(mat, wo, normal, basis, s3, sample_2d(tab, spp, 0, sample, scr, bset),
@@ -462,18 +514,155 @@ __global__ void __launch_bounds__(256) k_shade(const DScene* __restrict__ scp, T
                 f3 no = point + normal * signum(dot(normal, se.wi)) * offset_by; // create_rays, src/hitable.rs:42-47
                 pool.ox[P] = no.x; pool.oy[P] = no.y; pool.oz[P] = no.z;
                 pool.dx[P] = se.wi.x; pool.dy[P] = se.wi.y; pool.dz[P] = se.wi.z;
-                pool.tr[P] = thr.x; pool.tg[P] = thr.y; pool.tb[P] = thr.z;
+                // the finish kernel still needs the OLD throughput: park the new one beside the slot
+                nee.nthr[j] = thr.x; nee.nthr[cap + j] = thr.y; nee.nthr[2 * cap + j] = thr.z;
                 is_alive = true;
             }
         } else {
             pool.term_key[P] = key | (depth == 0 ? 0x80000000u : 0u); // Background at depth 0, else Color
         }
-        pool.lr[P] = rad.x; pool.lg[P] = rad.y; pool.lb[P] = rad.z;
+        nee.flags[j] = (uint8_t)(flags | (is_alive ? 1u : 0u));
     }
     alive[j] = is_alive ? 1 : 0;
     uint64_t m = __ballot(is_alive);
     if (lane == 0) bgrp_cnt[j >> 6] = (uint8_t)__popcll(m);
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+}
+
+// Dense list of the pending (sample, slot) pairs: every thread scans SCAN_ITEMS vis bytes, the block
+// scans the counts and reserves its range with ONE atomic (a per-wave append on a single counter
+// saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue").  List order is irrelevant: results are
+// written back by index.
+constexpr uint32_t SCAN_ITEMS = 16;
+__global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, uint32_t n_slots, uint32_t* __restrict__ job_count) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const uint32_t n_ids = ns * n_slots, cap = nee.cap;
+    const uint32_t first = blockIdx.x * (256 * SCAN_ITEMS) + threadIdx.x;
+    uint32_t refs[SCAN_ITEMS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < SCAN_ITEMS; r++) {
+        const uint32_t id = first + r * 256;
+        refs[r] = INVALID;
+        if (id < n_ids) {
+            const uint32_t ref = (id / n_slots) * cap + (id % n_slots);
+            if (nee.vis[ref] == 2) { refs[r] = ref; cnt++; }
+        }
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(cnt, s_wave, &tot);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(job_count, tot) : 0u;
+    __syncthreads();
+    uint32_t w = s_base + ex;
+#pragma unroll
+    for (uint32_t r = 0; r < SCAN_ITEMS; r++)
+        if (refs[r] != INVALID) nee.job_ref[w++] = refs[r];
+}
+
+// TracedSDF::occluded (src/sdf.rs:25-57) for the pending shadow segments, persistent waves (see k_extend).
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, Nee nee, const uint32_t* __restrict__ job_count,
+                                                 uint32_t* __restrict__ head, unsigned long long* __restrict__ evals_out) {
+    const DScene& sc = *scp;
+    const uint32_t lane = lane_id();
+    const uint32_t n_jobs = *job_count, nh = sc.n_hitables, jc = nee.jobcap;
+    const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+    bool has = false, first = false, nan = false;
+    uint32_t ref = 0, k = 0, m = 0, evals = 0;
+    f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0};
+    float max_dist = 0.0f, t = 0.0f;
+    auto next_sdf = [&]() { // advance k to the next TracedSDF; none left -> the segment is visible
+        while (k < nh && sc.h[k].kind == RAYN_HITABLE_SPHERE) k++;
+        if (k >= nh) { nee.vis[ref] = 1; has = false; }
+        else first = true;
+    };
+    for (;;) {
+        for (;;) {
+            const uint64_t need = __ballot(!has);
+            if (need == 0) break;
+            if (cur == end) {
+                if (exhausted) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n_jobs) { exhausted = true; break; }
+                cur = base;
+                end = min(base + CHUNK, n_jobs);
+            }
+            const uint32_t rank = mbcnt(need), avail = end - cur;
+            if (!has && rank < avail) {
+                ref = nee.job_ref[cur + rank]; // [sample][slot]
+                start = f3{nee.job_geo[ref], nee.job_geo[jc + ref], nee.job_geo[2 * jc + ref]};
+                const f3 e = f3{nee.job_geo[3 * jc + ref], nee.job_geo[4 * jc + ref], nee.job_geo[5 * jc + ref]};
+                dir = e - start;
+                max_dist = mag(dir);
+                dir = dir / max_dist;
+                k = 0; has = true;
+                next_sdf();
+            }
+            cur += min((uint32_t)__popcll(need), avail);
+        }
+        const uint64_t act = __ballot(has);
+        if (act == 0) break;
+        const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)__builtin_ctzll(act));
+        const DHitable& h = sc.h[ku];
+        if (has && k == ku) {
+            const f3 p = first ? start : muladd3(dir, t, start);
+            const float dist = sdf_dist<COUNT>(h, p, evals);
+            int res = -1; // -1 keep marching, 0 occluded, 1 this SDF does not occlude
+            if (first) {
+                t = dist; nan = dist != dist; first = false; m = 0;
+                if (sc.max_vis_marches == 0) res = ((dist < 0.0001f) && !((dist > max_dist) || nan)) ? 0 : 1;
+                else if ((t > max_dist) || nan) res = 1;
+            } else {
+                if (__builtin_fabsf(dist) < fmaxs(c0, c1 * t)) res = 0;
+                else {
+                    t = t + dist; m++;
+                    if (m == sc.max_vis_marches || (t > max_dist) || nan) res = 1;
+                }
+            }
+            if (res == 0) { nee.vis[ref] = 0; has = false; }
+            else if (res == 1) { k++; next_sdf(); }
+        }
+    }
+    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+}
+
+__global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__ scp, const uint32_t* __restrict__ bq, uint32_t n_slots,
+                                                       Pool pool, Nee nee) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_slots) return;
+    const uint32_t P = bq[j];
+    if (P == INVALID) return;
+    const DScene& sc = *scp;
+    const uint32_t flags = nee.flags[j], cap = nee.cap, nl = sc.n_lights, VM = sc.vm;
+    if (flags & 6u) {
+        f3 rad = f3{pool.lr[P], pool.lg[P], pool.lb[P]};
+        const f3 thr = f3{pool.tr[P], pool.tg[P], pool.tb[P]};
+        if (flags & 2u) { // src/integrator.rs:82-93
+            const float corr = (float)nl / 4.0f, vol_T = nee.T[j];
+            for (uint32_t i = 0; i < 4; i++) {
+                const f3 x = f3{nee.x[(i * 3 + 0) * cap + j], nee.x[(i * 3 + 1) * cap + j], nee.x[(i * 3 + 2) * cap + j]};
+                const float occ = (float)nee.vis[i * cap + j];
+                const f3 li = x * occ / nee.pdf[i * cap + j];
+                rad = rad + li * thr * corr * vol_T;
+            }
+        }
+        if (flags & 4u) { // src/integrator.rs:99-131
+            const float corr = (float)nl / 4.0f / (float)VM;
+            for (uint32_t s = 4; s < 4 + 4 * VM; s++) {
+                const f3 x = f3{nee.x[(s * 3 + 0) * cap + j], nee.x[(s * 3 + 1) * cap + j], nee.x[(s * 3 + 2) * cap + j]};
+                const float occ = (float)nee.vis[s * cap + j];
+                const f3 li = x * occ / nee.pdf[s * cap + j];
+                rad = rad + li * thr * corr * sc.rho_s * nee.aux[(s - 4) * cap + j];
+            }
+        }
+        pool.lr[P] = rad.x; pool.lg[P] = rad.y; pool.lb[P] = rad.z;
+    }
+    if (flags & 1u) { pool.tr[P] = nee.nthr[j]; pool.tg[P] = nee.nthr[cap + j]; pool.tb[P] = nee.nthr[2 * cap + j]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,9 +819,24 @@ void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const
     hipLaunchKernelGGL(k_bin_scatter, grid_for(n_entries, 256), dim3(256), 0, s, nclass, q, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
 }
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
-                  uint32_t n_slots, Pool pool, uint8_t* alive, uint8_t* bgrp_cnt, unsigned long long* evals) {
-    if (count) hipLaunchKernelGGL(k_shade<true>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, alive, bgrp_cnt, evals);
-    else hipLaunchKernelGGL(k_shade<false>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, alive, bgrp_cnt, evals);
+                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
+                  unsigned long long* evals, ShadeHooks hooks) {
+    (void)hipMemsetAsync(counters + 1, 0, 8, s); // [1] shadow job count, [2] shadow queue head
+    hooks.before(0);
+    if (count) hipLaunchKernelGGL(k_shade_setup<true>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, evals + 1);
+    else hipLaunchKernelGGL(k_shade_setup<false>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, evals + 1);
+    hooks.after(0);
+    if (has_sdf) {
+        hooks.before(1);
+        hipLaunchKernelGGL(k_shadow_list, grid_for(ns * n_slots, 256 * SCAN_ITEMS), dim3(256), 0, s, nee, ns, n_slots, counters + 1);
+        const dim3 grid(std::min<uint32_t>(PERSISTENT_BLOCKS, (ns * n_slots + 255) / 256));
+        if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, evals + 2);
+        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, evals + 2);
+        hooks.after(1);
+    }
+    hooks.before(2);
+    hipLaunchKernelGGL(k_shade_finish, grid_for(n_slots, 256), dim3(256), 0, s, sc, bq, n_slots, pool, nee);
+    hooks.after(2);
 }
 void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
                             const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn) {

@@ -22,7 +22,7 @@ using namespace rayn;
 
 namespace {
 
-enum ProfClass { PC_RAYGEN = 0, PC_EXTEND, PC_BIN, PC_SHADE, PC_COMPACT, PC_RESOLVE, PC_COUNT };
+enum ProfClass { PC_RAYGEN = 0, PC_EXTEND, PC_BIN, PC_SHADE, PC_COMPACT, PC_RESOLVE, PC_SHADOW, PC_FINISH, PC_COUNT };
 
 struct ProfRec { int cls; hipEvent_t a, b; };
 
@@ -51,7 +51,7 @@ struct rayn_ctx {
     uint32_t* h_totals = nullptr; // pinned
     unsigned long long* d_evals = nullptr;
     rayn_stats stats;
-    unsigned long long evals_extend = 0, evals_shade = 0;
+    unsigned long long evals[3] = {0, 0, 0}; // extend, shade_setup (normals), shadow
     bool profiling = false, counting = false;
     size_t batch_paths = (size_t)1 << 25;
     std::vector<ProfRec> prof;
@@ -183,6 +183,7 @@ void collect_profile(rayn_ctx* ctx) {
     ctx->prof.clear();
     ctx->stats.ms_raygen = ms[PC_RAYGEN]; ctx->stats.ms_extend = ms[PC_EXTEND]; ctx->stats.ms_bin = ms[PC_BIN];
     ctx->stats.ms_shade = ms[PC_SHADE]; ctx->stats.ms_compact = ms[PC_COMPACT]; ctx->stats.ms_resolve = ms[PC_RESOLVE];
+    ctx->stats.ms_shadow = ms[PC_SHADOW]; ctx->stats.ms_finish = ms[PC_FINISH];
 }
 
 struct BatchTile { uint32_t tile_index; DTile d; };
@@ -226,7 +227,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         if (!cur.empty()) { max_pool = std::max(max_pool, pool); max_tiles = std::max(max_tiles, cur.size()); batches.push_back(std::move(cur)); }
     }
     memset(&ctx->stats, 0, sizeof ctx->stats);
-    ctx->evals_extend = ctx->evals_shade = 0;
+    ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
     if (batches.empty()) return RAYN_OK;
 
     // ---- device memory: one arena sized for the largest batch
@@ -245,6 +246,10 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     acc(max_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                           // tiles, pgrp_tile
     for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
     acc(2, 4); acc(8, 4);
+    const uint32_t NS = 4 + (ctx->world.has_scattering ? 4 * p->volume_marches : 0); // NEE samples per shading point
+    const size_t JOBCAP = (size_t)NS * BCAP;
+    acc(NS * 3 * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);
+    acc(JOBCAP, 4); acc(6 * JOBCAP, 4);
     if (need > ctx->arena.cap) {
         if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
         ctx->arena.base = nullptr; ctx->arena.cap = 0;
@@ -272,12 +277,17 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     uint32_t* tile_total = A.take<uint32_t>(max_tiles); uint32_t* tile_valid = A.take<uint32_t>(max_tiles); uint32_t* tile_out_base = A.take<uint32_t>(max_tiles);
     uint32_t* d_totals = A.take<uint32_t>(2);
     uint32_t* d_counters = A.take<uint32_t>(8);
+    Nee nee;
+    nee.cap = (uint32_t)BCAP; nee.jobcap = (uint32_t)JOBCAP;
+    nee.x = A.take<float>(NS * 3 * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
+    nee.vis = A.take<uint8_t>(NS * BCAP); nee.T = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
+    nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float>(6 * JOBCAP);
     if (A.off > A.cap) return fail(ctx, RAYN_ERR_OOM, "internal: arena under-sized");
 
     hipEvent_t ev_a = get_event(ctx), ev_b = get_event(ctx);
     HIPCHK(hipEventRecord(ev_a, stream));
     HIPCHK(hipMemcpyAsync(ctx->d_scene, &hs, sizeof hs, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(ctx->d_evals, 0, 16, stream));
+    HIPCHK(hipMemsetAsync(ctx->d_evals, 0, 32, stream));
     const Tables tab{d_s1, d_s2, d_fis};
     const bool count = ctx->counting;
 
@@ -326,7 +336,15 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
                 launch_bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
             }
             ctx->stats.queue_bytes += (uint64_t)n_entries * (4 + 1 + 4) + (uint64_t)n_slots * 4;
-            { Timed t(ctx, stream, PC_SHADE); launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, alive, bgrp_cnt, ctx->d_evals + 1); }
+            {
+                static const int cls[3] = {PC_SHADE, PC_SHADOW, PC_FINISH};
+                struct HookState { rayn_ctx* ctx; hipStream_t s; Timed* cur; } hst{ctx, stream, nullptr};
+                ShadeHooks hooks;
+                hooks.user = &hst;
+                hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->ctx, h->s, cls[i]); };
+                hooks.after_fn = [](void* u, int) { HookState* h = (HookState*)u; delete h->cur; h->cur = nullptr; };
+                launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks);
+            }
             ctx->stats.launches_shade++;
             ctx->stats.shaded_slots += n_slots;
             {
@@ -359,9 +377,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     ctx->event_pool.push_back(ev_a); ctx->event_pool.push_back(ev_b);
     if (ctx->profiling) collect_profile(ctx);
     if (count) {
-        unsigned long long ev[2] = {0, 0};
-        HIPCHK(hipMemcpy(ev, ctx->d_evals, 16, hipMemcpyDeviceToHost));
-        ctx->evals_extend = ev[0]; ctx->evals_shade = ev[1];
+        HIPCHK(hipMemcpy(ctx->evals, ctx->d_evals, 24, hipMemcpyDeviceToHost));
     }
     return RAYN_OK;
 }
@@ -380,7 +396,7 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof ctx->stats);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_scene, sizeof(DScene)) != hipSuccess || hipMalloc((void**)&ctx->d_evals, 16) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_scene, sizeof(DScene)) != hipSuccess || hipMalloc((void**)&ctx->d_evals, 32) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_totals, 16) != hipSuccess) {
         delete ctx;
         return RAYN_ERR_HIP;
@@ -467,10 +483,9 @@ int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals) {
     ctx->counting = count_evals != 0;
     return RAYN_OK;
 }
-int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t* extend_evals, uint64_t* shade_evals) {
-    if (!ctx || !extend_evals || !shade_evals) return RAYN_ERR_INVALID_ARG;
-    *extend_evals = ctx->evals_extend;
-    *shade_evals = ctx->evals_shade;
+int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]) {
+    if (!ctx || !out) return RAYN_ERR_INVALID_ARG;
+    for (int i = 0; i < 3; i++) out[i] = ctx->evals[i];
     return RAYN_OK;
 }
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths) {

@@ -75,9 +75,9 @@ class Context:
         return s.as_dict()
 
     def eval_counts(self):
-        a, b = C.c_uint64(), C.c_uint64()
-        self._chk(self._L.rayn_hip_get_eval_counts(self.h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        out = (C.c_uint64 * 3)()
+        self._chk(self._L.rayn_hip_get_eval_counts(self.h, out))
+        return {"extend": out[0], "shade_setup": out[1], "shadow": out[2]}
 
     def render_host(self, params, tables, out=None):
         """rayn_hip_render_frame with host (numpy) buffers.  Returns the film dict."""

@@ -148,12 +148,13 @@ def test_instrumented_variant_matches(gpu_ctx, oracle):
     gpu_ctx.upload_world(wd)
     gpu_ctx.set_profiling(True, True)
     out = gpu_ctx.render_host(p, tabs)
-    ex, sh = gpu_ctx.eval_counts()
+    ev = gpu_ctx.eval_counts()
     st = gpu_ctx.stats()
     gpu_ctx.set_profiling(False, False)
     assert film_equal_bits(out, ref)
-    assert 0 < ex + sh <= ctr.dist_evals  # oracle counts all 4 lanes of every packet call
-    assert st["ms_extend"] > 0 and st["ms_shade"] > 0
+    assert all(v > 0 for v in ev.values())
+    assert sum(ev.values()) <= ctr.dist_evals  # oracle counts all 4 lanes of every packet call
+    assert st["ms_extend"] > 0 and st["ms_shade"] > 0 and st["ms_shadow"] > 0
 
 
 def test_errors_instead_of_panics(gpu_ctx):
