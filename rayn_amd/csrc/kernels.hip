@@ -77,6 +77,12 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
 // loop iteration evaluates the SDF on (almost) all 64 lanes.  Results are written by entry/pool
 // index, so the fetch order never influences the output.
 constexpr uint32_t CHUNK = 256;
+#ifndef RAYN_REFILL_MIN_EXTEND
+#define RAYN_REFILL_MIN_EXTEND 16
+#endif
+#ifndef RAYN_REFILL_MIN_SHADOW
+#define RAYN_REFILL_MIN_SHADOW 8
+#endif
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, uint32_t depth, const uint32_t* __restrict__ q,
@@ -87,6 +93,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
     const Thr th = make_thr(sc, depth);
     const uint32_t nh = sc.n_hitables;
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
+    constexpr uint32_t REFILL_MIN = RAYN_REFILL_MIN_EXTEND;
     uint32_t cur = 0, end = 0; // wave-uniform chunk window
     bool exhausted = false;
     // per-lane ray state
@@ -108,39 +115,51 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
         ent_obj[ent] = (uint8_t)id;
         has = false;
     };
+    // 'has': the lane owns a ray; 'marching': it is inside a TracedSDF march.  A lane that leaves its march
+    // parks (has && !marching) until at least REFILL_MIN lanes are parked/idle: the sphere epilogue, the
+    // result stores and the queue fetch then run once for many lanes instead of once per finishing lane.
+    bool marching = false;
     for (;;) {
-        for (;;) { // refill idle lanes until every lane is inside a march (or the queue is empty)
-            const uint64_t need = __ballot(!has);
-            if (need == 0) break;
-            if (cur == end) {
-                if (exhausted) break;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, CHUNK);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n_entries) { exhausted = true; break; }
-                cur = base;
-                end = min(base + CHUNK, n_entries);
-            }
-            const uint32_t rank = mbcnt(need), avail = end - cur;
-            if (!has && rank < avail) {
-                ent = cur + rank;
-                P = q[ent];
-                if (P == INVALID) ent_obj[ent] = (uint8_t)OBJ_NONE;
-                else {
-                    o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
-                    d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
-                    closest = sc.t_max; id = OBJ_NONE; k = 0; has = true;
-                    advance();
+        const uint64_t parked = __ballot(!marching);
+        if (parked != 0 && ((uint32_t)__popcll(parked) >= REFILL_MIN || exhausted)) {
+            if (has && !marching) { advance(); marching = has; } // epilogue of the finished march
+            for (;;) { // refill idle lanes until every lane is inside a march (or the queue is empty)
+                const uint64_t need = __ballot(!has);
+                if (need == 0) break;
+                if (cur == end) {
+                    if (exhausted) break;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_entries) { exhausted = true; break; }
+                    cur = base;
+                    end = min(base + CHUNK, n_entries);
                 }
+                const uint32_t rank = mbcnt(need), avail = end - cur;
+                if (!has && rank < avail) {
+                    ent = cur + rank;
+                    P = q[ent];
+                    if (P == INVALID) ent_obj[ent] = (uint8_t)OBJ_NONE;
+                    else {
+                        o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
+                        d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
+                        closest = sc.t_max; id = OBJ_NONE; k = 0; has = true;
+                        advance();
+                        marching = has;
+                    }
+                }
+                cur += min((uint32_t)__popcll(need), avail);
             }
-            cur += min((uint32_t)__popcll(need), avail);
         }
-        const uint64_t act = __ballot(has);
-        if (act == 0) break;
+        const uint64_t act = __ballot(marching);
+        if (act == 0) {
+            if (__ballot(has) == 0 && exhausted) break;
+            continue;
+        }
         // all lanes of this step evaluate the same SDF object (scenes normally hold exactly one)
         const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)__builtin_ctzll(act));
         const DHitable& h = sc.h[ku];
-        if (has && k == ku) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
+        if (marching && k == ku) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
             const f3 p = first ? o : muladd3(d, t, o);
             const float dist = sdf_dist<COUNT>(h, p, evals);
             bool done;
@@ -154,7 +173,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
             if (done) {
                 if (t < closest) { closest = t; id = k; }
                 k++;
-                advance();
+                marching = false;
             }
         }
     }
@@ -579,31 +598,34 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
         if (k >= nh) { nee.vis[ref] = 1; has = false; }
         else first = true;
     };
+    constexpr uint32_t REFILL_MIN = RAYN_REFILL_MIN_SHADOW;
     for (;;) {
-        for (;;) {
-            const uint64_t need = __ballot(!has);
-            if (need == 0) break;
-            if (cur == end) {
-                if (exhausted) break;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, CHUNK);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n_jobs) { exhausted = true; break; }
-                cur = base;
-                end = min(base + CHUNK, n_jobs);
+        const uint64_t idle = __ballot(!has);
+        if (idle != 0 && ((uint32_t)__popcll(idle) >= REFILL_MIN) && !exhausted) {
+            for (;;) {
+                const uint64_t need = __ballot(!has);
+                if (need == 0) break;
+                if (cur == end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_jobs) { exhausted = true; break; }
+                    cur = base;
+                    end = min(base + CHUNK, n_jobs);
+                }
+                const uint32_t rank = mbcnt(need), avail = end - cur;
+                if (!has && rank < avail) {
+                    ref = nee.job_ref[cur + rank]; // [sample][slot]
+                    start = f3{nee.job_geo[ref], nee.job_geo[jc + ref], nee.job_geo[2 * jc + ref]};
+                    const f3 e = f3{nee.job_geo[3 * jc + ref], nee.job_geo[4 * jc + ref], nee.job_geo[5 * jc + ref]};
+                    dir = e - start;
+                    max_dist = mag(dir);
+                    dir = dir / max_dist;
+                    k = 0; has = true;
+                    next_sdf();
+                }
+                cur += min((uint32_t)__popcll(need), avail);
             }
-            const uint32_t rank = mbcnt(need), avail = end - cur;
-            if (!has && rank < avail) {
-                ref = nee.job_ref[cur + rank]; // [sample][slot]
-                start = f3{nee.job_geo[ref], nee.job_geo[jc + ref], nee.job_geo[2 * jc + ref]};
-                const f3 e = f3{nee.job_geo[3 * jc + ref], nee.job_geo[4 * jc + ref], nee.job_geo[5 * jc + ref]};
-                dir = e - start;
-                max_dist = mag(dir);
-                dir = dir / max_dist;
-                k = 0; has = true;
-                next_sdf();
-            }
-            cur += min((uint32_t)__popcll(need), avail);
         }
         const uint64_t act = __ballot(has);
         if (act == 0) break;
