@@ -33,6 +33,7 @@ WORKLOADS = {
     "c2": ("s1", 1920, 1080, 64, 8, "1920x1080, 256 spp, 8 bounces, MandelBox SDF (reference fractal), volumes off [BASELINE configs[1]]"),
     "c3": ("s2", 1920, 1080, 256, 8, "1920x1080, 1024 spp, 8 bounces, MandelBox SDF + homogeneous volume [BASELINE configs[2]]"),
     "c1": ("s0", 256, 256, 4, 4, "256x256, 16 spp, 4 bounces, single-sphere SDF [BASELINE configs[0]]"),
+    "mid": ("s1", 960, 540, 16, 8, "960x540, 64 spp, 8 bounces, MandelBox (profiling-sized)"),
     "small": ("s1", 480, 270, 4, 3, "480x270, 16 spp, 3 bounces, MandelBox (quick check)"),
 }
 

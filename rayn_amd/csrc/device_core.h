@@ -121,6 +121,22 @@ RD float fis_sample(const float* __restrict__ inverse_cdf, float u) {
 }
 
 // ---- SDFs (src/sdf.rs:104-188; sdfu::Sphere) ---------------------------------------------------------
+// Correctly rounded n/d for finite normal n, d whose quotient is a normal number: the same Newton-Raphson
+// + residual-correction steps hipcc emits for an IEEE '/', minus v_div_scale / v_div_fixup (which only act
+// on extreme exponents and specials).  22 VALU cycles instead of 36.  The host enables it per object only
+// when the fold constants keep every operand in [2^-60, 2^60] (DHitable::fast_div); tests check it
+// against IEEE division over that whole range.
+RD float div_nr(float n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    float q = n * r;
+    const float e1 = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e2, r, q);
+}
+
 template <bool COUNT>
 RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
     if (COUNT) evals++;
@@ -128,23 +144,30 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
         const f3 offset = p;
         float dr = 1.0f;
         const float l = h.box_l, nl = -h.box_l, s = h.scale;
+        const float mrs = h.min_rad_sq, frs = h.fixed_rad_sq, inf = __builtin_inff();
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
-        for (uint32_t i = 0; i < h.iterations; i++) {
-            // box_fold: clamped(-l, l).mul_add(2, -p)
-            p.x = muladd(__builtin_amdgcn_fmed3f(p.x, nl, l), 2.0f, -p.x);
-            p.y = muladd(__builtin_amdgcn_fmed3f(p.y, nl, l), 2.0f, -p.y);
-            p.z = muladd(__builtin_amdgcn_fmed3f(p.z, nl, l), 2.0f, -p.z);
-            // sphere_fold
-            float r2 = mag_sq(p);
-            float m = __builtin_fmaxf(1.0f, h.fixed_rad_sq / __builtin_fmaxf(h.min_rad_sq, r2));
-            p.x *= m; p.y *= m; p.z *= m;
-            dr *= m;
-            p.x = muladd(p.x, s, offset.x);
-            p.y = muladd(p.y, s, offset.y);
-            p.z = muladd(p.z, s, offset.z);
-            dr = muladd(-dr, s, 1.0f);
+#define RAYN_FOLD_BODY(DIV)                                                                   \
+        for (uint32_t i = 0; i < h.iterations; i++) {                                         \
+            /* box_fold: clamped(-l, l).mul_add(2, -p) */                                     \
+            p.x = muladd(__builtin_amdgcn_fmed3f(p.x, nl, l), 2.0f, -p.x);                    \
+            p.y = muladd(__builtin_amdgcn_fmed3f(p.y, nl, l), 2.0f, -p.y);                    \
+            p.z = muladd(__builtin_amdgcn_fmed3f(p.z, nl, l), 2.0f, -p.z);                    \
+            /* sphere_fold */                                                                 \
+            const float r2 = mag_sq(p);                                                       \
+            /* med3(r2, mrs, +inf) == max(mrs, r2) without the canonicalising v_max of fmaxf */  \
+            const float m = __builtin_fmaxf(1.0f, DIV(frs, __builtin_amdgcn_fmed3f(r2, mrs, inf))); \
+            p.x *= m; p.y *= m; p.z *= m;                                                     \
+            dr *= m;                                                                          \
+            p.x = muladd(p.x, s, offset.x);                                                   \
+            p.y = muladd(p.y, s, offset.y);                                                   \
+            p.z = muladd(p.z, s, offset.z);                                                   \
+            dr = muladd(-dr, s, 1.0f);                                                        \
         }
+#define RAYN_DIV_IEEE(a, b) ((a) / (b))
+        if (h.fast_div) { RAYN_FOLD_BODY(div_nr) } else { RAYN_FOLD_BODY(RAYN_DIV_IEEE) }
+#undef RAYN_FOLD_BODY
+#undef RAYN_DIV_IEEE
         return mag(p) / __builtin_fabsf(dr);
     }
     return mag(p) - h.sdf_radius;

@@ -13,7 +13,7 @@ struct DHitable {
     uint32_t kind, material, sdf_kind, iterations;
     f3 center; float radius_sq;           // Sphere: f32x4::from(radius*radius), src/sphere.rs:31,52
     float box_l, min_rad_sq, fixed_rad_sq, scale; // MandelBox (src/sdf.rs:114-122,151-158,172-179)
-    float sdf_radius; uint32_t _pad[3];
+    float sdf_radius; uint32_t fast_div; uint32_t _pad[2];
 };
 struct DMaterial { uint32_t kind, receives_light; float exponent, _pad; f3 a; float _p1; f3 b; float _p2; };
 struct DLight { f3 pos; float rad; f3 emission; float _pad; };

@@ -806,7 +806,9 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
     case 2: r = dm_cosf(a[i]); break;
     case 3: r = dm_tanf(a[i]); break;
     case 4: r = dm_atan2f(a[i], b[i]); break;
-    default: r = dm_powf(a[i], b[i]); break;
+    case 5: r = dm_powf(a[i], b[i]); break;
+    case 6: r = div_nr(a[i], b[i]); break;
+    default: r = a[i] / b[i]; break;
     }
     out[i] = r;
 }

@@ -101,6 +101,10 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
         d.fixed_rad_sq = h.fixed_radius * h.fixed_radius;
         d.scale = h.scale;
         d.sdf_radius = h.sdf_radius;
+        {   // div_nr is exact while numerator, denominator and quotient stay far from the exponent limits
+            const float lo = 8.6736174e-19f /* 2^-60 */, hi = 1.1529215e18f /* 2^60 */;
+            d.fast_div = (d.min_rad_sq >= lo && d.min_rad_sq <= hi && d.fixed_rad_sq >= lo && d.fixed_rad_sq <= hi) ? 1u : 0u;
+        }
         if (h.kind == RAYN_HITABLE_TRACED_SDF) {
             s.n_sdf++;
             if (h.sdf_kind != RAYN_SDF_SPHERE && h.sdf_kind != RAYN_SDF_MANDELBOX) return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown sdf_kind");

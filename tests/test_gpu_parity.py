@@ -30,6 +30,24 @@ def test_detmath_bit_exact(gpu_ctx, oracle, op, lo, hi):
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
 
 
+def test_fast_division_is_ieee(gpu_ctx):
+    """div_nr (the fold's division) == IEEE division bit for bit over the operand range the host enables it for."""
+    import ctypes as C
+    from rayn_amd._lib import lib
+    rng = np.random.default_rng(5)
+    n = 4_000_000
+    expo = rng.integers(-60, 61, n)
+    den = (rng.uniform(1.0, 2.0, n) * np.exp2(expo.astype(np.float64))).astype(np.float32)
+    num = np.full(n, np.float32(1.9 * 1.9), np.float32)
+    num[n // 2:] = (rng.uniform(1.0, 2.0, n - n // 2) * np.exp2(rng.integers(-30, 31, n - n // 2).astype(np.float64))).astype(np.float32)
+    keep = np.abs(np.log2(num.astype(np.float64) / den)) < 100  # quotient stays a normal float
+    num, den = num[keep], den[keep]
+    out = np.zeros_like(num)
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib().rayn_hip_probe_detmath(gpu_ctx.h, 6, fp(num), fp(den), fp(out), num.size) == 0
+    assert np.array_equal(out.view(np.uint32), (num / den).view(np.uint32))
+
+
 def _probe_setup(gpu_ctx, name):
     wd, p = case(name, 64, 64, 1, 3)
     gpu_ctx.upload_world(wd)
