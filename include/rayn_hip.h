@@ -213,7 +213,7 @@ uint32_t rayn_tile_count(uint32_t width, uint32_t height, uint32_t tile_w, uint3
 int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals);
 /* out[0] k_extend (closest-hit marches), out[1] k_shade_setup (normal estimation), out[2] k_shadow (NEE visibility) */
 int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
-/* path-pool capacity per batch of tiles (default 2^25 paths ~ 3.3 GB of HBM). */
+/* path-pool capacity per batch of tiles (default 2^27 paths: ~40 GB of HBM for a scene without volume). */
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
 /* 0: a*b+c unfused (reference default build), 1: fused (see include/rayn_detmath.h). */
 int rayn_hip_fma_policy(void);

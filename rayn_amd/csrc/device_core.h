@@ -145,6 +145,8 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
         float dr = 1.0f;
         const float l = h.box_l, nl = -h.box_l, s = h.scale;
         const float mrs = h.min_rad_sq, frs = h.fixed_rad_sq, inf = __builtin_inff();
+        // if min_rad_sq > fixed_rad_sq the quotient is < 1 for every r2: never enter the block
+        const float frs_eff = mrs <= frs ? frs : -1.0f;
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
 #define RAYN_FOLD_BODY(DIV)                                                                   \
@@ -153,12 +155,17 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
             p.x = muladd(__builtin_amdgcn_fmed3f(p.x, nl, l), 2.0f, -p.x);                    \
             p.y = muladd(__builtin_amdgcn_fmed3f(p.y, nl, l), 2.0f, -p.y);                    \
             p.z = muladd(__builtin_amdgcn_fmed3f(p.z, nl, l), 2.0f, -p.z);                    \
-            /* sphere_fold */                                                                 \
+            /* sphere_fold: mul = max(1, R2 / max(r2min, r2)).  For r2 >= R2 (and for NaN) the quotient  \
+               is <= 1, mul is exactly 1 and the two multiplies are identities, so the whole block is     \
+               skipped - the compiler branches around it when no lane of the wave needs it, which is the  \
+               common case once an orbit escapes.  For r2 < R2 the quotient is >= 1: max(1, q) == q. */   \
             const float r2 = mag_sq(p);                                                       \
-            /* med3(r2, mrs, +inf) == max(mrs, r2) without the canonicalising v_max of fmaxf */  \
-            const float m = __builtin_fmaxf(1.0f, DIV(frs, __builtin_amdgcn_fmed3f(r2, mrs, inf))); \
-            p.x *= m; p.y *= m; p.z *= m;                                                     \
-            dr *= m;                                                                          \
+            if (r2 < frs_eff) {                                                               \
+                /* med3(r2, mrs, +inf) == max(mrs, r2) without the canonicalising v_max of fmaxf */ \
+                const float m = DIV(frs, __builtin_amdgcn_fmed3f(r2, mrs, inf));              \
+                p.x *= m; p.y *= m; p.z *= m;                                                 \
+                dr *= m;                                                                      \
+            }                                                                                 \
             p.x = muladd(p.x, s, offset.x);                                                   \
             p.y = muladd(p.y, s, offset.y);                                                   \
             p.z = muladd(p.z, s, offset.z);                                                   \

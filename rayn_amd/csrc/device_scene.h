@@ -39,5 +39,6 @@ struct DTile { uint32_t x0, y0, ew, eh; uint32_t pool_base, n_paths; uint32_t _p
 
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
 constexpr uint32_t OBJ_NONE = 0xFFu;
+constexpr uint32_t TERM_NONE = 0xFFu;
 
 } // namespace rayn

@@ -16,7 +16,8 @@ struct Pool {
     float* hit_t;
     uint8_t* hit_obj;
     uint32_t *pix, *samp;
-    uint32_t* term_key; // bit31 Background, bits 26..30 depth, bits 0..25 binned slot; INVALID = dropped
+    uint32_t* term_key; // binned slot at which the path emitted its Color/Background sample
+    uint8_t* term_info; // depth (bits 0..6) | Background flag (bit 7); TERM_NONE = no sample emitted (dropped ray)
     float *n0x, *n0y, *n0z;
     uint8_t* obj0;
 };
@@ -30,10 +31,10 @@ struct Nee {
     float* T;      // [cap]       volume transmission of the segment
     float* nthr;   // [3][cap]    throughput of the spawned ray
     uint8_t* flags; // [cap]      bit0 alive, bit1 surface NEE, bit2 volume NEE
-    uint32_t cap;
+    size_t cap;
     uint32_t* job_ref; // [jobcap] dense list of pending [sample*cap + slot] indices (k_shadow_list)
     float* job_geo;    // [6][jobcap] pending shadow segments: start xyz, end xyz at [sample*cap + slot]
-    uint32_t jobcap;
+    size_t jobcap;
 };
 
 // the host brackets the three shading kernels with its profiling events through these hooks
@@ -45,12 +46,19 @@ struct ShadeHooks {
     void after(int i) const { if (after_fn) after_fn(user, i); }
 };
 
+// launch tuning of the persistent march kernels
+struct Tuning {
+    uint32_t persistent_blocks = 256 * 8; // 256 CUs x 8 blocks of 4 waves = 32 waves per CU
+    uint32_t refill_min_extend = 16;      // parked lanes before a wave runs epilogue + queue fetch
+    uint32_t refill_min_shadow = 8;
+};
+
 struct Tables { const float* __restrict__ s1d; const float* __restrict__ s2d; const float* __restrict__ fis; };
 
 void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
                    Pool pool, uint32_t* q, uint32_t n_pool);
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, uint32_t* head, unsigned long long* evals);
+                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, uint32_t* head, unsigned long long* evals, const Tuning& tun);
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
                       const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
                       uint32_t* tile_valid);
@@ -60,7 +68,7 @@ void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const
                         const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq);
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
                   uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
-                  unsigned long long* evals, ShadeHooks hooks);
+                  unsigned long long* evals, ShadeHooks hooks, const Tuning& tun);
 void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
                             const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn);
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,

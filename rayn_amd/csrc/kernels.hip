@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
     const DScene& sc = *scp;
     const DTile tile = tiles[pgrp_tile[P >> 6]];
     const uint32_t p = P - tile.pool_base;
-    pool.term_key[P] = INVALID;
+    pool.term_info[P] = (uint8_t)TERM_NONE;
     pool.obj0[P] = (uint8_t)OBJ_NONE;
     if (p >= tile.n_paths) { q[P] = INVALID; return; }
     const uint32_t spp = sc.spp;
@@ -77,23 +77,16 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
 // loop iteration evaluates the SDF on (almost) all 64 lanes.  Results are written by entry/pool
 // index, so the fetch order never influences the output.
 constexpr uint32_t CHUNK = 256;
-#ifndef RAYN_REFILL_MIN_EXTEND
-#define RAYN_REFILL_MIN_EXTEND 16
-#endif
-#ifndef RAYN_REFILL_MIN_SHADOW
-#define RAYN_REFILL_MIN_SHADOW 8
-#endif
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, uint32_t depth, const uint32_t* __restrict__ q,
                                                  uint32_t n_entries, Pool pool, uint8_t* __restrict__ ent_obj,
-                                                 uint32_t* __restrict__ head, unsigned long long* __restrict__ evals_out) {
+                                                 uint32_t* __restrict__ head, uint32_t REFILL_MIN, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
     const Thr th = make_thr(sc, depth);
     const uint32_t nh = sc.n_hitables;
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
-    constexpr uint32_t REFILL_MIN = RAYN_REFILL_MIN_EXTEND;
     uint32_t cur = 0, end = 0; // wave-uniform chunk window
     bool exhausted = false;
     // per-lane ray state
@@ -394,7 +387,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
             else vol_picks |= (unsigned long long)packed << (16 * (k - 1));
         }
     }
-    const uint32_t cap = nee.cap;
+    const size_t cap = nee.cap;
     const bool scene_has_sdf = sc.n_sdf > 0;
     bool is_alive = false;
     uint32_t evals = 0, flags = 0;
@@ -402,7 +395,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     // job_geo[..][s*cap + slot]; k_shadow scans all (sample, slot) pairs.  (A compacted job list would need
     // one atomic per wave per sample on a single counter - that alone cost 0.5 s per frame.)
     auto park_job = [&](uint32_t s, f3 a, f3 b) {
-        const uint32_t idx = s * cap + j, jc = nee.jobcap;
+        const size_t idx = s * cap + j, jc = nee.jobcap;
         nee.job_geo[idx] = a.x; nee.job_geo[jc + idx] = a.y; nee.job_geo[2 * jc + idx] = a.z;
         nee.job_geo[3 * jc + idx] = b.x; nee.job_geo[4 * jc + idx] = b.y; nee.job_geo[5 * jc + idx] = b.z;
     };
@@ -507,7 +500,6 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     }
     // ---- BSDF sample, roulette, AOVs, termination (src/integrator.rs:134-203)
     if (valid) {
-        uint32_t key = (depth << 26) | j;
         if (receives) {
             const Basis basis = orthonormal_basis(normal);
             const uint32_t bset = set2 + 4 + 4 * VM; // comps 8+8*VM .. +3
@@ -527,7 +519,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
                 pool.obj0[P] = (uint8_t)obj;
             }
             if (depth >= sc.max_bounces || s4 < rr) {
-                pool.term_key[P] = key; // ChannelSample::Color(ray.radiance)
+                pool.term_key[P] = j; pool.term_info[P] = (uint8_t)depth; // ChannelSample::Color(ray.radiance)
             } else {
                 if (!any_nan(nthr)) thr = nthr;
                 f3 no = point + normal * signum(dot(normal, se.wi)) * offset_by; // create_rays, src/hitable.rs:42-47
@@ -538,7 +530,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
                 is_alive = true;
             }
         } else {
-            pool.term_key[P] = key | (depth == 0 ? 0x80000000u : 0u); // Background at depth 0, else Color
+            pool.term_key[P] = j; pool.term_info[P] = (uint8_t)(depth | (depth == 0 ? 0x80u : 0u)); // Background at depth 0, else Color
         }
         nee.flags[j] = (uint8_t)(flags | (is_alive ? 1u : 0u));
     }
@@ -556,7 +548,8 @@ constexpr uint32_t SCAN_ITEMS = 16;
 __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, uint32_t n_slots, uint32_t* __restrict__ job_count) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
-    const uint32_t n_ids = ns * n_slots, cap = nee.cap;
+    const uint32_t n_ids = ns * n_slots;
+    const size_t cap = nee.cap;
     const uint32_t first = blockIdx.x * (256 * SCAN_ITEMS) + threadIdx.x;
     uint32_t refs[SCAN_ITEMS];
     uint32_t cnt = 0;
@@ -565,7 +558,7 @@ __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, uint3
         const uint32_t id = first + r * 256;
         refs[r] = INVALID;
         if (id < n_ids) {
-            const uint32_t ref = (id / n_slots) * cap + (id % n_slots);
+            const uint32_t ref = (uint32_t)((id / n_slots) * cap + (id % n_slots)); // < 2^32, checked on the host
             if (nee.vis[ref] == 2) { refs[r] = ref; cnt++; }
         }
     }
@@ -582,10 +575,11 @@ __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, uint3
 // TracedSDF::occluded (src/sdf.rs:25-57) for the pending shadow segments, persistent waves (see k_extend).
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, Nee nee, const uint32_t* __restrict__ job_count,
-                                                 uint32_t* __restrict__ head, unsigned long long* __restrict__ evals_out) {
+                                                 uint32_t* __restrict__ head, uint32_t REFILL_MIN, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
-    const uint32_t n_jobs = *job_count, nh = sc.n_hitables, jc = nee.jobcap;
+    const uint32_t n_jobs = *job_count, nh = sc.n_hitables;
+    const size_t jc = nee.jobcap;
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
@@ -598,7 +592,6 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
         if (k >= nh) { nee.vis[ref] = 1; has = false; }
         else first = true;
     };
-    constexpr uint32_t REFILL_MIN = RAYN_REFILL_MIN_SHADOW;
     for (;;) {
         const uint64_t idle = __ballot(!has);
         if (idle != 0 && ((uint32_t)__popcll(idle) >= REFILL_MIN) && !exhausted) {
@@ -660,7 +653,8 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
     const uint32_t P = bq[j];
     if (P == INVALID) return;
     const DScene& sc = *scp;
-    const uint32_t flags = nee.flags[j], cap = nee.cap, nl = sc.n_lights, VM = sc.vm;
+    const uint32_t flags = nee.flags[j], nl = sc.n_lights, VM = sc.vm;
+    const size_t cap = nee.cap;
     if (flags & 6u) {
         f3 rad = f3{pool.lr[P], pool.lg[P], pool.lb[P]};
         const f3 thr = f3{pool.tr[P], pool.tg[P], pool.tb[P]};
@@ -694,14 +688,15 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
 // the pixel's spp paths by termination key in LDS (bitonic) and three lanes (r,g,b) accumulate them
 // sequentially.  Alpha/WorldNormal are depth-0 samples, ordered (object, sample).
 // ------------------------------------------------------------------------------------------------
-RD void bitonic_sort_lds(uint32_t* key, uint32_t* val, uint32_t n) {
+template <typename K>
+RD void bitonic_sort_lds(K* key, uint32_t* val, uint32_t n) {
     for (uint32_t k = 2; k <= n; k <<= 1)
         for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
             for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
                 uint32_t l = i ^ jj;
                 if (l > i) {
                     bool up = (i & k) == 0;
-                    uint32_t a = key[i], b = key[l];
+                    K a = key[i], b = key[l];
                     if ((a > b) == up) {
                         key[i] = b; key[l] = a;
                         uint32_t t = val[i]; val[i] = val[l]; val[l] = t;
@@ -715,9 +710,11 @@ RD void bitonic_sort_lds(uint32_t* key, uint32_t* val, uint32_t n) {
 __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
                                                  float* __restrict__ out_color, float* __restrict__ out_alpha,
                                                  float* __restrict__ out_background, float* __restrict__ out_normal, uint32_t n_sort) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* key = smem;
-    uint32_t* val = smem + n_sort;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long smem64[];
+    unsigned long long* key = smem64;
+    uint32_t* val = (uint32_t*)(smem64 + n_sort);
+    uint32_t* key32 = val + n_sort;
+    constexpr unsigned long long NOKEY = ~0ull;
     const DScene& sc = *scp;
     const DTile tile = tiles[blockIdx.y];
     const uint32_t lpix = blockIdx.x;
@@ -729,8 +726,11 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
     const float n = (float)spp;
     // ---- Color / Background in (depth, slot) order
     for (uint32_t i = threadIdx.x; i < n_sort; i += 64) {
-        uint32_t k = INVALID;
-        if (i < spp) { uint32_t tk = pool.term_key[P0 + i]; if (tk != INVALID) k = tk & 0x7FFFFFFFu; }
+        unsigned long long k = NOKEY;
+        if (i < spp) {
+            const uint32_t info = pool.term_info[P0 + i];
+            if (info != TERM_NONE) k = ((unsigned long long)(info & 0x7Fu) << 32) | pool.term_key[P0 + i];
+        }
         key[i] = k;
         val[i] = i;
     }
@@ -740,10 +740,10 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
         const float* src = threadIdx.x == 0 ? pool.lr : (threadIdx.x == 1 ? pool.lg : pool.lb);
         float c = 0.0f, b = 0.0f;
         for (uint32_t e = 0; e < spp; e++) {
-            if (key[e] == INVALID) break;
+            if (key[e] == NOKEY) break;
             const uint32_t P = P0 + val[e];
             const float v = src[P];
-            if (pool.term_key[P] & 0x80000000u) b += v; else c += v;
+            if (pool.term_info[P] & 0x80u) b += v; else c += v;
         }
         out_color[3 * fi + threadIdx.x] = c / n;
         out_background[3 * fi + threadIdx.x] = b / n;
@@ -753,16 +753,16 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
     for (uint32_t i = threadIdx.x; i < n_sort; i += 64) {
         uint32_t k = INVALID;
         if (i < spp) { uint32_t ob = pool.obj0[P0 + i]; if (ob != OBJ_NONE) k = (ob << 16) | i; }
-        key[i] = k;
+        key32[i] = k;
         val[i] = i;
     }
     __syncthreads();
-    bitonic_sort_lds(key, val, n_sort);
+    bitonic_sort_lds(key32, val, n_sort);
     if (threadIdx.x < 4) {
         const float* src = threadIdx.x == 0 ? pool.n0x : (threadIdx.x == 1 ? pool.n0y : pool.n0z);
         float a = 0.0f;
         for (uint32_t e = 0; e < spp; e++) {
-            if (key[e] == INVALID) break;
+            if (key32[e] == INVALID) break;
             a += threadIdx.x == 3 ? 1.0f : src[P0 + val[e]];
         }
         if (threadIdx.x == 3) out_alpha[fi] = a / n;
@@ -815,18 +815,18 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
 
 // ---- launch wrappers (declared in kernels.h) -----------------------------------------------------
 static inline dim3 grid_for(uint32_t n, uint32_t block) { return dim3((n + block - 1) / block); }
-constexpr uint32_t PERSISTENT_BLOCKS = 256 * 8; // 256 CUs x 8 blocks of 4 waves = 32 waves per CU
+
 
 void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
                    Pool pool, uint32_t* q, uint32_t n_pool) {
     hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool);
 }
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, uint32_t* head, unsigned long long* evals) {
+                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, uint32_t* head, unsigned long long* evals, const Tuning& tun) {
     (void)hipMemsetAsync(head, 0, 4, s);
-    const dim3 grid(std::min<uint32_t>(PERSISTENT_BLOCKS, (n_entries + 255) / 256));
-    if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, evals);
-    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, evals);
+    const dim3 grid(std::min<uint32_t>(tun.persistent_blocks, (n_entries + 255) / 256));
+    if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, tun.refill_min_extend, evals);
+    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, tun.refill_min_extend, evals);
     hipLaunchKernelGGL(k_group_hist, grid_for(n_entries, 256), dim3(256), 0, s, nclass, ent_obj, n_entries, grp_cnt);
 }
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
@@ -844,7 +844,7 @@ void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const
 }
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
                   uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
-                  unsigned long long* evals, ShadeHooks hooks) {
+                  unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
     (void)hipMemsetAsync(counters + 1, 0, 8, s); // [1] shadow job count, [2] shadow queue head
     hooks.before(0);
     if (count) hipLaunchKernelGGL(k_shade_setup<true>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, evals + 1);
@@ -853,9 +853,9 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
     if (has_sdf) {
         hooks.before(1);
         hipLaunchKernelGGL(k_shadow_list, grid_for(ns * n_slots, 256 * SCAN_ITEMS), dim3(256), 0, s, nee, ns, n_slots, counters + 1);
-        const dim3 grid(std::min<uint32_t>(PERSISTENT_BLOCKS, (ns * n_slots + 255) / 256));
-        if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, evals + 2);
-        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, evals + 2);
+        const dim3 grid(std::min<uint32_t>(tun.persistent_blocks, (ns * n_slots + 255) / 256));
+        if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, tun.refill_min_shadow, evals + 2);
+        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, tun.refill_min_shadow, evals + 2);
         hooks.after(1);
     }
     hooks.before(2);
@@ -870,7 +870,7 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {
     uint32_t n_sort = 1;
     while (n_sort < spp) n_sort <<= 1;
-    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 8, s, sc, tiles, pool, out_color, out_alpha, out_background,
+    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 16, s, sc, tiles, pool, out_color, out_alpha, out_background,
                        out_normal, n_sort);
 }
 void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {

@@ -53,7 +53,8 @@ struct rayn_ctx {
     rayn_stats stats;
     unsigned long long evals[3] = {0, 0, 0}; // extend, shade_setup (normals), shadow
     bool profiling = false, counting = false;
-    size_t batch_paths = (size_t)1 << 25;
+    size_t batch_paths = (size_t)1 << 27;
+    Tuning tun;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
 };
@@ -153,7 +154,7 @@ int validate(rayn_ctx* ctx, const rayn_frame_params* p) {
     if (!ctx->have_world) return fail(ctx, RAYN_ERR_NO_WORLD, "rayn_hip_upload_world has not been called");
     if (!p->width || !p->height || !p->samples || !p->tile_w || !p->tile_h) return fail(ctx, RAYN_ERR_INVALID_ARG, "zero-sized frame, tile or sample count");
     if (p->volume_marches < 2 || p->volume_marches > 4) return fail(ctx, RAYN_ERR_INVALID_ARG, "volume_marches must be in [2,4] (samples_1d[3],[4] are indexed, src/integrator.rs:138,175)");
-    if (p->max_bounces > 30) return fail(ctx, RAYN_ERR_INVALID_ARG, "max_bounces > 30 does not fit the 5-bit depth field of the termination key");
+    if (p->max_bounces > 120) return fail(ctx, RAYN_ERR_INVALID_ARG, "max_bounces > 120 does not fit the 7-bit depth field of the termination record");
     if (p->samples * 4 > 65535) return fail(ctx, RAYN_ERR_INVALID_ARG, "spp > 65535 unsupported");
     if (p->tile_w * p->tile_h > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile larger than 1024 pixels unsupported");
     return RAYN_OK;
@@ -238,11 +239,11 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     const size_t CAP = max_pool;                                   // pool slots
     const size_t QCAP = CAP + max_tiles * 64;                      // ray queue slots (tile tails)
     const size_t BCAP = CAP + max_tiles * (SCAN_NC_BIN * 3 + 64);  // binned slots (x4 bin padding + tails)
-    if (BCAP >= ((size_t)1 << 26)) return fail(ctx, RAYN_ERR_INVALID_ARG, "batch too large for the 26-bit slot field; lower RAYN_HIP_BATCH_PATHS");
+
     const size_t QG = QCAP / 64 + 1, BG = BCAP / 64 + 1;
     size_t need = 0;
     auto acc = [&](size_t n, size_t sz) { need += (n * sz + 255) & ~(size_t)255; };
-    acc(CAP, 4 * 14); acc(CAP, 1); acc(CAP, 8); acc(CAP, 4); acc(CAP, 12); acc(CAP, 1);           // pool (each array separately below)
+    acc(CAP, 4 * 14); acc(CAP, 1); acc(CAP, 8); acc(CAP, 4); acc(CAP, 1); acc(CAP, 12); acc(CAP, 1);           // pool (each array separately below)
     need += 256 * 32;                                                                              // alignment slack for the separate pool arrays
     acc(QCAP, 4); acc(QCAP, 4); acc(BCAP, 4); acc(QCAP, 1); acc(BCAP, 1);                          // q, qn, bq, ent_obj, alive
     acc(QG * SCAN_NC_BIN, 1); acc(QG * SCAN_NC_BIN, 4); acc(QG, 4);                                // grp_cnt, grp_base, grp_tile
@@ -252,6 +253,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     acc(2, 4); acc(8, 4);
     const uint32_t NS = 4 + (ctx->world.has_scattering ? 4 * p->volume_marches : 0); // NEE samples per shading point
     const size_t JOBCAP = (size_t)NS * BCAP;
+    if (JOBCAP >= ((size_t)1 << 32) || BCAP >= ((size_t)1 << 31)) return fail(ctx, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
     acc(NS * 3 * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);
     acc(JOBCAP, 4); acc(6 * JOBCAP, 4);
     if (need > ctx->arena.cap) {
@@ -269,7 +271,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     pool.lr = A.take<float>(CAP); pool.lg = A.take<float>(CAP); pool.lb = A.take<float>(CAP);
     pool.tr = A.take<float>(CAP); pool.tg = A.take<float>(CAP); pool.tb = A.take<float>(CAP);
     pool.hit_t = A.take<float>(CAP); pool.hit_obj = A.take<uint8_t>(CAP);
-    pool.pix = A.take<uint32_t>(CAP); pool.samp = A.take<uint32_t>(CAP); pool.term_key = A.take<uint32_t>(CAP);
+    pool.pix = A.take<uint32_t>(CAP); pool.samp = A.take<uint32_t>(CAP); pool.term_key = A.take<uint32_t>(CAP); pool.term_info = A.take<uint8_t>(CAP);
     pool.n0x = A.take<float>(CAP); pool.n0y = A.take<float>(CAP); pool.n0z = A.take<float>(CAP); pool.obj0 = A.take<uint8_t>(CAP);
     uint32_t* q = A.take<uint32_t>(QCAP); uint32_t* qn = A.take<uint32_t>(QCAP); uint32_t* bq = A.take<uint32_t>(BCAP);
     uint8_t* ent_obj = A.take<uint8_t>(QCAP); uint8_t* alive = A.take<uint8_t>(BCAP);
@@ -282,7 +284,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     uint32_t* d_totals = A.take<uint32_t>(2);
     uint32_t* d_counters = A.take<uint32_t>(8);
     Nee nee;
-    nee.cap = (uint32_t)BCAP; nee.jobcap = (uint32_t)JOBCAP;
+    nee.cap = BCAP; nee.jobcap = JOBCAP;
     nee.x = A.take<float>(NS * 3 * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
     nee.vis = A.take<uint8_t>(NS * BCAP); nee.T = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
     nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float>(6 * JOBCAP);
@@ -321,7 +323,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         uint32_t n_entries = (uint32_t)n_pool;
         uint32_t* qcur = q; uint32_t* qnext = qn;
         for (uint32_t depth = 0; n_entries > 0; depth++) {
-            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, d_counters, ctx->d_evals); }
+            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, d_counters, ctx->d_evals, ctx->tun); }
             ctx->stats.launches_extend++;
             {
                 Timed t(ctx, stream, PC_BIN);
@@ -347,7 +349,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
                 hooks.user = &hst;
                 hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->ctx, h->s, cls[i]); };
                 hooks.after_fn = [](void* u, int) { HookState* h = (HookState*)u; delete h->cur; h->cur = nullptr; };
-                launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks);
+                launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks, ctx->tun);
             }
             ctx->stats.launches_shade++;
             ctx->stats.shaded_slots += n_slots;
@@ -407,6 +409,9 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     }
     if (const char* e = getenv("RAYN_HIP_BATCH_PATHS")) { long long v = atoll(e); if (v >= 4096) ctx->batch_paths = (size_t)v; }
     if (const char* e = getenv("RAYN_HIP_PROFILE")) ctx->profiling = atoi(e) != 0;
+    if (const char* e = getenv("RAYN_HIP_REFILL_EXTEND")) ctx->tun.refill_min_extend = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("RAYN_HIP_REFILL_SHADOW")) ctx->tun.refill_min_shadow = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("RAYN_HIP_PERSISTENT_BLOCKS")) ctx->tun.persistent_blocks = (uint32_t)std::max(1, atoi(e));
     *out = ctx;
     return RAYN_OK;
 }

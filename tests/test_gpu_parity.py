@@ -139,7 +139,7 @@ def test_batching_is_invisible(gpu_ctx, oracle):
     gpu_ctx.set_batch_paths(4096)
     b = gpu_ctx.render_host(p, tabs)
     assert gpu_ctx.stats()["batches"] > 1
-    gpu_ctx.set_batch_paths(1 << 25)
+    gpu_ctx.set_batch_paths(1 << 27)
     assert film_equal_bits(a, b)
 
 
