@@ -450,7 +450,13 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
                 float dist = mag(wi);
                 wi = wi / dist;
                 f3 occlude_point = point + normal * signum(dot(normal, wi)) * offset_by;
-                f3 f = bsdf_f(mat, wo, wi, normal) * fmaxs(dot(normal, wi), 0.0f);
+                const float ndw = dot(normal, wi);
+                const float cosw = fmaxs(ndw, 0.0f);
+                f3 f;
+                // light below the horizon: bsdf.f(..) * 0 is +0 whenever f is finite, which it is for finite
+                // inputs with a non-degenerate half vector -> skip the pow/normalize of BSDF::f (bit-identical)
+                if (cosw == 0.0f && ndw == ndw && mag_sq(wo + wi) > 0.0f) f = f3{0.0f, 0.0f, 0.0f};
+                else f = bsdf_f(mat, wo, wi, normal) * cosw;
                 float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dist) : 1.0f;
                 f3 x = L.emission * f * tr;
                 nee.x[(i * 3 + 0) * cap + j] = x.x; nee.x[(i * 3 + 1) * cap + j] = x.y; nee.x[(i * 3 + 2) * cap + j] = x.z;
@@ -707,13 +713,22 @@ RD void bitonic_sort_lds(K* key, uint32_t* val, uint32_t n) {
         }
 }
 
+// true when key[0..n) is already non-decreasing (wave-wide; n_sort is a power of two >= 1)
+template <typename K>
+RD bool is_sorted_lds(const K* key, uint32_t n) {
+    bool ok = true;
+    for (uint32_t i = threadIdx.x; i + 1 < n; i += 64) ok = ok && !(key[i] > key[i + 1]);
+    return __ballot(!ok) == 0;
+}
+
 __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
                                                  float* __restrict__ out_color, float* __restrict__ out_alpha,
                                                  float* __restrict__ out_background, float* __restrict__ out_normal, uint32_t n_sort) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem64[];
-    unsigned long long* key = smem64;
-    uint32_t* val = (uint32_t*)(smem64 + n_sort);
-    uint32_t* key32 = val + n_sort;
+    unsigned long long* key = smem64;           // [n_sort]
+    uint32_t* val = (uint32_t*)(smem64 + n_sort); // [n_sort]
+    uint32_t* key32 = val + n_sort;             // [n_sort]
+    float* stage = (float*)(key32 + n_sort);    // [3][n_sort] values in accumulation order
     constexpr unsigned long long NOKEY = ~0ull;
     const DScene& sc = *scp;
     const DTile tile = tiles[blockIdx.y];
@@ -735,15 +750,23 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
         val[i] = i;
     }
     __syncthreads();
-    bitonic_sort_lds(key, val, n_sort);
+    if (!is_sorted_lds(key, n_sort)) bitonic_sort_lds(key, val, n_sort); // sky-only pixels arrive sorted
+    // all lanes stage the values in accumulation order; Background samples carry the sign bit of val
+    for (uint32_t e = threadIdx.x; e < spp; e += 64) {
+        if (key[e] != NOKEY) {
+            const uint32_t P = P0 + val[e];
+            stage[e] = pool.lr[P]; stage[n_sort + e] = pool.lg[P]; stage[2 * n_sort + e] = pool.lb[P];
+            if (pool.term_info[P] & 0x80u) val[e] |= 0x80000000u;
+        }
+    }
+    __syncthreads();
     if (threadIdx.x < 3) {
-        const float* src = threadIdx.x == 0 ? pool.lr : (threadIdx.x == 1 ? pool.lg : pool.lb);
+        const float* src = stage + threadIdx.x * n_sort;
         float c = 0.0f, b = 0.0f;
         for (uint32_t e = 0; e < spp; e++) {
             if (key[e] == NOKEY) break;
-            const uint32_t P = P0 + val[e];
-            const float v = src[P];
-            if (pool.term_info[P] & 0x80u) b += v; else c += v;
+            const float v = src[e];
+            if (val[e] & 0x80000000u) b += v; else c += v;
         }
         out_color[3 * fi + threadIdx.x] = c / n;
         out_background[3 * fi + threadIdx.x] = b / n;
@@ -757,13 +780,25 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
         val[i] = i;
     }
     __syncthreads();
-    bitonic_sort_lds(key32, val, n_sort);
+    if (key32[0] == INVALID && is_sorted_lds(key32, n_sort)) { // no depth-0 surface hit at all: INVALID everywhere
+        if (threadIdx.x == 3) out_alpha[fi] = 0.0f / n;
+        else if (threadIdx.x < 3) out_normal[3 * fi + threadIdx.x] = 0.0f / n;
+        return;
+    }
+    if (!is_sorted_lds(key32, n_sort)) bitonic_sort_lds(key32, val, n_sort);
+    for (uint32_t e = threadIdx.x; e < spp; e += 64) {
+        if (key32[e] != INVALID) {
+            const uint32_t P = P0 + val[e];
+            stage[e] = pool.n0x[P]; stage[n_sort + e] = pool.n0y[P]; stage[2 * n_sort + e] = pool.n0z[P];
+        }
+    }
+    __syncthreads();
     if (threadIdx.x < 4) {
-        const float* src = threadIdx.x == 0 ? pool.n0x : (threadIdx.x == 1 ? pool.n0y : pool.n0z);
+        const float* src = stage + (threadIdx.x % 3) * n_sort;
         float a = 0.0f;
         for (uint32_t e = 0; e < spp; e++) {
             if (key32[e] == INVALID) break;
-            a += threadIdx.x == 3 ? 1.0f : src[P0 + val[e]];
+            a += threadIdx.x == 3 ? 1.0f : src[e];
         }
         if (threadIdx.x == 3) out_alpha[fi] = a / n;
         else out_normal[3 * fi + threadIdx.x] = a / n;
@@ -870,7 +905,7 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {
     uint32_t n_sort = 1;
     while (n_sort < spp) n_sort <<= 1;
-    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 16, s, sc, tiles, pool, out_color, out_alpha, out_background,
+    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 28, s, sc, tiles, pool, out_color, out_alpha, out_background,
                        out_normal, n_sort);
 }
 void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {

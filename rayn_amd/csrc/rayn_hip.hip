@@ -155,7 +155,7 @@ int validate(rayn_ctx* ctx, const rayn_frame_params* p) {
     if (!p->width || !p->height || !p->samples || !p->tile_w || !p->tile_h) return fail(ctx, RAYN_ERR_INVALID_ARG, "zero-sized frame, tile or sample count");
     if (p->volume_marches < 2 || p->volume_marches > 4) return fail(ctx, RAYN_ERR_INVALID_ARG, "volume_marches must be in [2,4] (samples_1d[3],[4] are indexed, src/integrator.rs:138,175)");
     if (p->max_bounces > 120) return fail(ctx, RAYN_ERR_INVALID_ARG, "max_bounces > 120 does not fit the 7-bit depth field of the termination record");
-    if (p->samples * 4 > 65535) return fail(ctx, RAYN_ERR_INVALID_ARG, "spp > 65535 unsupported");
+    if (p->samples > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "spp > 4096 unsupported (film resolve sorts a pixel's samples in LDS)");
     if (p->tile_w * p->tile_h > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile larger than 1024 pixels unsupported");
     return RAYN_OK;
 }
