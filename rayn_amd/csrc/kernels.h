@@ -9,17 +9,17 @@ namespace rayn {
 
 constexpr uint32_t SCAN_NC_BIN = 16; // = RAYN_MAX_HITABLES: classes of the bin scan
 
-// SoA path pool (device pointers)
+// Path pool (device pointers): one slot per camera path, records of 16 bytes so that a scattered
+// access costs one 128-bit gather per record instead of four 32-bit ones (the shade kernels were
+// bound by the address path of the vector memory unit, not by bandwidth).
 struct Pool {
-    float *ox, *oy, *oz, *dx, *dy, *dz, *time;
-    float *lr, *lg, *lb, *tr, *tg, *tb;
-    float* hit_t;
-    uint8_t* hit_obj;
-    uint32_t *pix, *samp;
+    float4* geo0;  // origin.xyz, dir.x
+    float4* geo1;  // dir.y, dir.z, hit_t, bits: hit object (8) | sample index << 8
+    float4* col0;  // radiance.rgb, throughput.r
+    float4* col1;  // throughput.g, throughput.b, bits: film pixel index, ray time
+    float4* aov;   // depth-0 WorldNormal sample xyz, bits: depth-0 object (OBJ_NONE = no Alpha/Normal sample)
     uint32_t* term_key; // binned slot at which the path emitted its Color/Background sample
     uint8_t* term_info; // depth (bits 0..6) | Background flag (bit 7); TERM_NONE = no sample emitted (dropped ray)
-    float *n0x, *n0y, *n0z;
-    uint8_t* obj0;
 };
 
 // per-slot NEE records + the shadow-job list (see k_shade_setup)
@@ -53,8 +53,15 @@ struct Tuning {
     uint32_t refill_min_shadow = 8;
 };
 
-struct Tables { const float* __restrict__ s1d; const float* __restrict__ s2d; const float* __restrict__ fis; };
+// sample tables: the reference layout (src/sampler.rs:11-15) + a per-(depth, sample) packed copy built at
+// frame start: record = [3+VM 1-D sets | pad to 8 | 12+8*VM 2-D components] of that depth, 16-byte aligned,
+// so a shading point fetches its ~20 random numbers with five 128-bit gathers instead of ~20 32-bit ones.
+struct Tables {
+    const float* __restrict__ s1d; const float* __restrict__ s2d; const float* __restrict__ fis;
+    const float4* __restrict__ rec; uint32_t rec_stride; // float4 per record; record index = depth * spp + sample
+};
 
+void launch_pack_tables(hipStream_t s, Tables tab, float4* out, uint32_t spp, uint32_t depths, uint32_t n1, uint32_t n2);
 void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
                    Pool pool, uint32_t* q, uint32_t n_pool);
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,

@@ -26,6 +26,16 @@ RD uint32_t mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Per-(depth, sample) packed copy of the sample tables (see Tables in kernels.h).  One thread per record.
+__global__ void __launch_bounds__(256) k_pack_tables(Tables tab, float4* __restrict__ out, uint32_t spp, uint32_t depths, uint32_t n1, uint32_t n2) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= spp * depths) return;
+    const uint32_t depth = r / spp, s = r % spp;
+    float* dst = (float*)(out + (size_t)r * tab.rec_stride);
+    for (uint32_t k = 0; k < 8; k++) dst[k] = k < n1 ? tab.s1d[s + spp * (1 + k + depth * n1)] : 0.0f; // sets 1+k+depth*n1, src/film.rs:572
+    for (uint32_t c = 0; c < n2; c++) dst[8 + c] = tab.s2d[(c & 1) + s * 2 + spp * 2 * (2 + (c >> 1) + depth * (n2 / 2))]; // src/film.rs:580-587
+}
+
 // ------------------------------------------------------------------------------------------------
 // a8: tile ray-gen loop, src/film.rs:456-529 (+ sample_uv :695-709, Camera::get_rays).
 // One thread per pool slot.  Pool order inside a tile: x outer, y inner, sample innermost.
@@ -39,7 +49,7 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
     const DTile tile = tiles[pgrp_tile[P >> 6]];
     const uint32_t p = P - tile.pool_base;
     pool.term_info[P] = (uint8_t)TERM_NONE;
-    pool.obj0[P] = (uint8_t)OBJ_NONE;
+    pool.aov[P] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(OBJ_NONE));
     if (p >= tile.n_paths) { q[P] = INVALID; return; }
     const uint32_t spp = sc.spp;
     const uint32_t s = p % spp, lpix = p / spp;
@@ -56,13 +66,10 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
     float l0 = sample_2d(tab, spp, 0, s, scr, 1), l1 = sample_2d(tab, spp, 1, s, scr, 1);
     f3 o, d;
     camera_ray(sc.cam, uvx, uvy, l0, l1, &o, &d);
-    pool.ox[P] = o.x; pool.oy[P] = o.y; pool.oz[P] = o.z;
-    pool.dx[P] = d.x; pool.dy[P] = d.y; pool.dz[P] = d.z;
-    pool.time[P] = time;
-    pool.lr[P] = 0.0f; pool.lg[P] = 0.0f; pool.lb[P] = 0.0f; // WRay::new: radiance 0, throughput 1
-    pool.tr[P] = 1.0f; pool.tg[P] = 1.0f; pool.tb[P] = 1.0f;
-    pool.pix[P] = pix;
-    pool.samp[P] = s;
+    pool.geo0[P] = make_float4(o.x, o.y, o.z, d.x);
+    pool.geo1[P] = make_float4(d.y, d.z, 0.0f, __uint_as_float(OBJ_NONE | (s << 8)));
+    pool.col0[P] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); // WRay::new: radiance 0, throughput 1
+    pool.col1[P] = make_float4(1.0f, 1.0f, __uint_as_float(pix), time);
     q[P] = P;
 }
 
@@ -91,7 +98,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
     bool exhausted = false;
     // per-lane ray state
     bool has = false, first = false, nan = false;
-    uint32_t ent = 0, P = 0, k = 0, id = OBJ_NONE, m = 0, evals = 0;
+    uint32_t ent = 0, P = 0, k = 0, id = OBJ_NONE, m = 0, evals = 0, sbits = 0;
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
     float closest = 0.0f, t = 0.0f;
     // fold over the hitables (src/hitable.rs:177-198) up to the next TracedSDF; finish the ray at the end
@@ -103,8 +110,8 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
             if (ts < closest) { closest = ts; id = k; }
             k++;
         }
-        pool.hit_t[P] = closest;
-        pool.hit_obj[P] = (uint8_t)id;
+        // hit_t + object byte into geo1.zw (the sample index in the upper bits is preserved)
+        *(float2*)(&pool.geo1[P].z) = make_float2(closest, __uint_as_float((sbits & ~0xFFu) | id));
         ent_obj[ent] = (uint8_t)id;
         has = false;
     };
@@ -134,8 +141,10 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
                     P = q[ent];
                     if (P == INVALID) ent_obj[ent] = (uint8_t)OBJ_NONE;
                     else {
-                        o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
-                        d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
+                        const float4 g0 = pool.geo0[P], g1 = pool.geo1[P];
+                        o = f3{g0.x, g0.y, g0.z};
+                        d = f3{g0.w, g1.x, g1.y};
+                        sbits = __float_as_uint(g1.w);
                         closest = sc.t_max; id = OBJ_NONE; k = 0; has = true;
                         advance();
                         marching = has;
@@ -366,12 +375,22 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     const uint32_t lane = lane_id();
     const uint32_t P = bq[j];
     const bool valid = P != INVALID;
-    const uint32_t spp = sc.spp, n1 = sc.n1, n2h = sc.n2 / 2, nl = sc.n_lights, VM = sc.vm;
+    const uint32_t spp = sc.spp, nl = sc.n_lights, VM = sc.vm;
     uint32_t sample = 0, pix = 0;
     float scr = 0.0f;
-    if (valid) { sample = pool.samp[P]; pix = pool.pix[P]; scr = scramble[pix]; }
-    const uint32_t set1 = 1 + depth * n1;  // 1-D set of samples_1d[0] at this depth, src/film.rs:568-574
-    const uint32_t set2 = 2 + depth * n2h; // 2-D set of samples_2d[0..1], src/film.rs:579-589
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, c0 = g0, c1 = g0;
+    if (valid) {
+        g0 = pool.geo0[P]; g1 = pool.geo1[P]; c0 = pool.col0[P]; c1 = pool.col1[P];
+        sample = __float_as_uint(g1.w) >> 8; pix = __float_as_uint(c1.z); scr = scramble[pix];
+    }
+    // this lane's random numbers of this depth (raw table values; the pixel scramble is added per use)
+    const float4* rec = tab.rec + (size_t)(depth * spp + sample) * tab.rec_stride;
+    const float4 r1d = rec[0];
+    const float r1d4 = rec[1].x;
+    auto s1 = [&](uint32_t k) { // samples_1d[k] of this depth, src/film.rs:568-574 + Samples::sample_1d
+        const float raw = k == 0 ? r1d.x : (k == 1 ? r1d.y : (k == 2 ? r1d.z : (k == 3 ? r1d.w : r1d4)));
+        return dm_fractf(raw + scr);
+    };
     // light picks: each lane draws an index from ITS 1-D sample; the packet's four picks are packed
     // 4 bits each (n_lights <= 16) so the rolled loops below need no register arrays.
     uint32_t surf_picks = 0;
@@ -379,7 +398,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     if (nl > 0) {
         const uint32_t base = lane & ~3u;
         for (uint32_t k = 0; k < 1 + VM; k++) {
-            uint32_t mine = light_index(sample_1d(tab, spp, sample, scr, set1 + k), nl);
+            uint32_t mine = light_index(s1(k), nl);
             uint32_t packed = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 4; i++) packed |= (uint32_t)__shfl(mine, base + i) << (4 * i);
@@ -410,12 +429,12 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     uint32_t obj = 0;
     bool receives = false;
     if (valid) {
-        o = f3{pool.ox[P], pool.oy[P], pool.oz[P]};
-        d = f3{pool.dx[P], pool.dy[P], pool.dz[P]};
-        rad = f3{pool.lr[P], pool.lg[P], pool.lb[P]};
-        thr = f3{pool.tr[P], pool.tg[P], pool.tb[P]};
-        t = pool.hit_t[P];
-        obj = pool.hit_obj[P];
+        o = f3{g0.x, g0.y, g0.z};
+        d = f3{g0.w, g1.x, g1.y};
+        rad = f3{c0.x, c0.y, c0.z};
+        thr = f3{c0.w, c1.x, c1.y};
+        t = g1.z;
+        obj = __float_as_uint(g1.w) & 0xFFu;
         const DHitable& h = sc.h[obj];
         point = muladd3(d, t, o); // WHit::point -> Ray::point_at
         if (h.kind == RAYN_HITABLE_SPHERE) { // src/sphere.rs:73-86
@@ -430,7 +449,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
         vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
         receives = sc.m[h.material].receives_light != 0;
         rad = rad + bsdf_le(sc.m[h.material], -d) * thr * vol_T;
-        pool.lr[P] = rad.x; pool.lg[P] = rad.y; pool.lb[P] = rad.z;
+        pool.col0[P] = make_float4(rad.x, rad.y, rad.z, c0.w); // throughput.r stays: k_shade_finish needs the old one
         nee.T[j] = vol_T;
     }
     const DMaterial& mat = sc.m[sc.h[obj].material];
@@ -443,7 +462,8 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
             if (!do_surf) nee.vis[i * cap + j] = 1; // nothing pending for this (sample, slot)
             else {
                 const DLight& L = sc.l[(surf_picks >> (4 * i)) & 15u];
-                float u0 = sample_2d(tab, spp, 0, sample, scr, set2 + i), u1 = sample_2d(tab, spp, 1, sample, scr, set2 + i);
+                const float4 rs = rec[2 + (i >> 1)]; // 2-D components 2i, 2i+1
+                float u0 = dm_fractf(((i & 1) ? rs.z : rs.x) + scr), u1 = dm_fractf(((i & 1) ? rs.w : rs.y) + scr);
                 f3 end_point; float pdf;
                 light_sample(L, u0, u1, point, &end_point, &pdf);
                 f3 wi = end_point - point;
@@ -475,15 +495,15 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     const bool do_vol = valid && sc.has_scatter && nl > 0;
     if (sc.has_scatter) {
         if (do_vol) flags |= 4u;
-        const float vsample = sample_1d(tab, spp, sample, scr, set1 + 1); // samples_1d[1] for every march
+        const float vsample = s1(1); // samples_1d[1] for every march
         for (uint32_t march = 0; march < VM; march++) {
             for (uint32_t i = 0; i < 4; i++) {
                 const uint32_t s = 4 + 4 * march + i;
                 if (!do_vol) nee.vis[s * cap + j] = 1;
                 else {
                     const DLight& L = sc.l[(uint32_t)(vol_picks >> (16 * march + 4 * i)) & 15u];
-                    const uint32_t set = set2 + 4 + 4 * march + i; // comps 8+8*march+2i, +1
-                    float u0 = sample_2d(tab, spp, 0, sample, scr, set), u1 = sample_2d(tab, spp, 1, sample, scr, set);
+                    const float4 rs = rec[4 + 2 * march + (i >> 1)]; // comps 8+8*march+2i, +1
+                    float u0 = dm_fractf(((i & 1) ? rs.z : rs.x) + scr), u1 = dm_fractf(((i & 1) ? rs.w : rs.y) + scr);
                     float vdist, vpdf;
                     light_sample_volume(L, vsample, o, d, t, &vdist, &vpdf);
                     f3 sp = o + d * vdist;
@@ -508,11 +528,10 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     if (valid) {
         if (receives) {
             const Basis basis = orthonormal_basis(normal);
-            const uint32_t bset = set2 + 4 + 4 * VM; // comps 8+8*VM .. +3
-            float s3 = sample_1d(tab, spp, sample, scr, set1 + 3), s4 = sample_1d(tab, spp, sample, scr, set1 + 4);
-            Scatter se = bsdf_scatter(mat, wo, normal, basis, s3, sample_2d(tab, spp, 0, sample, scr, bset),
-                                      sample_2d(tab, spp, 1, sample, scr, bset), sample_2d(tab, spp, 0, sample, scr, bset + 1),
-                                      sample_2d(tab, spp, 1, sample, scr, bset + 1));
+            const float4 rb = rec[4 + 2 * VM]; // comps 8+8*VM .. +3
+            float s3 = s1(3), s4 = s1(4);
+            Scatter se = bsdf_scatter(mat, wo, normal, basis, s3, dm_fractf(rb.x + scr), dm_fractf(rb.y + scr), dm_fractf(rb.z + scr),
+                                      dm_fractf(rb.w + scr));
             float ndl = __builtin_fabsf(dot(se.wi, normal));
             f3 nthr = thr * vol_T * se.f * ndl / se.pdf;
             float rr = 0.0f;
@@ -521,16 +540,15 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
                 nthr = nthr / (1.0f - rr);
             }
             if (depth == 0) { // Alpha + WorldNormal AOVs, src/integrator.rs:161-169
-                pool.n0x[P] = normal.x; pool.n0y[P] = normal.y; pool.n0z[P] = normal.z;
-                pool.obj0[P] = (uint8_t)obj;
+                pool.aov[P] = make_float4(normal.x, normal.y, normal.z, __uint_as_float(obj));
             }
             if (depth >= sc.max_bounces || s4 < rr) {
                 pool.term_key[P] = j; pool.term_info[P] = (uint8_t)depth; // ChannelSample::Color(ray.radiance)
             } else {
                 if (!any_nan(nthr)) thr = nthr;
                 f3 no = point + normal * signum(dot(normal, se.wi)) * offset_by; // create_rays, src/hitable.rs:42-47
-                pool.ox[P] = no.x; pool.oy[P] = no.y; pool.oz[P] = no.z;
-                pool.dx[P] = se.wi.x; pool.dy[P] = se.wi.y; pool.dz[P] = se.wi.z;
+                pool.geo0[P] = make_float4(no.x, no.y, no.z, se.wi.x);
+                *(float2*)(&pool.geo1[P].x) = make_float2(se.wi.y, se.wi.z);
                 // the finish kernel still needs the OLD throughput: park the new one beside the slot
                 nee.nthr[j] = thr.x; nee.nthr[cap + j] = thr.y; nee.nthr[2 * cap + j] = thr.z;
                 is_alive = true;
@@ -662,8 +680,10 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
     const uint32_t flags = nee.flags[j], nl = sc.n_lights, VM = sc.vm;
     const size_t cap = nee.cap;
     if (flags & 6u) {
-        f3 rad = f3{pool.lr[P], pool.lg[P], pool.lb[P]};
-        const f3 thr = f3{pool.tr[P], pool.tg[P], pool.tb[P]};
+        const float4 c0 = pool.col0[P];
+        const float2 c1 = *(const float2*)(&pool.col1[P].x);
+        f3 rad = f3{c0.x, c0.y, c0.z};
+        const f3 thr = f3{c0.w, c1.x, c1.y};
         if (flags & 2u) { // src/integrator.rs:82-93
             const float corr = (float)nl / 4.0f, vol_T = nee.T[j];
             for (uint32_t i = 0; i < 4; i++) {
@@ -682,9 +702,14 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
                 rad = rad + li * thr * corr * sc.rho_s * nee.aux[(s - 4) * cap + j];
             }
         }
-        pool.lr[P] = rad.x; pool.lg[P] = rad.y; pool.lb[P] = rad.z;
+        if (flags & 1u) { // survivor: publish the new throughput together with the radiance
+            pool.col0[P] = make_float4(rad.x, rad.y, rad.z, nee.nthr[j]);
+            *(float2*)(&pool.col1[P].x) = make_float2(nee.nthr[cap + j], nee.nthr[2 * cap + j]);
+        } else pool.col0[P] = make_float4(rad.x, rad.y, rad.z, c0.w);
+    } else if (flags & 1u) {
+        pool.col0[P].w = nee.nthr[j];
+        *(float2*)(&pool.col1[P].x) = make_float2(nee.nthr[cap + j], nee.nthr[2 * cap + j]);
     }
-    if (flags & 1u) { pool.tr[P] = nee.nthr[j]; pool.tg[P] = nee.nthr[cap + j]; pool.tb[P] = nee.nthr[2 * cap + j]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -755,7 +780,8 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
     for (uint32_t e = threadIdx.x; e < spp; e += 64) {
         if (key[e] != NOKEY) {
             const uint32_t P = P0 + val[e];
-            stage[e] = pool.lr[P]; stage[n_sort + e] = pool.lg[P]; stage[2 * n_sort + e] = pool.lb[P];
+            const float4 c = pool.col0[P];
+            stage[e] = c.x; stage[n_sort + e] = c.y; stage[2 * n_sort + e] = c.z;
             if (pool.term_info[P] & 0x80u) val[e] |= 0x80000000u;
         }
     }
@@ -775,7 +801,7 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
     // ---- Alpha / WorldNormal: depth-0 packets are object-major, then queue (= sample) order
     for (uint32_t i = threadIdx.x; i < n_sort; i += 64) {
         uint32_t k = INVALID;
-        if (i < spp) { uint32_t ob = pool.obj0[P0 + i]; if (ob != OBJ_NONE) k = (ob << 16) | i; }
+        if (i < spp) { uint32_t ob = __float_as_uint(pool.aov[P0 + i].w); if (ob != OBJ_NONE) k = (ob << 16) | i; }
         key32[i] = k;
         val[i] = i;
     }
@@ -789,7 +815,8 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
     for (uint32_t e = threadIdx.x; e < spp; e += 64) {
         if (key32[e] != INVALID) {
             const uint32_t P = P0 + val[e];
-            stage[e] = pool.n0x[P]; stage[n_sort + e] = pool.n0y[P]; stage[2 * n_sort + e] = pool.n0z[P];
+            const float4 a = pool.aov[P];
+            stage[e] = a.x; stage[n_sort + e] = a.y; stage[2 * n_sort + e] = a.z;
         }
     }
     __syncthreads();
@@ -852,6 +879,9 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
 static inline dim3 grid_for(uint32_t n, uint32_t block) { return dim3((n + block - 1) / block); }
 
 
+void launch_pack_tables(hipStream_t s, Tables tab, float4* out, uint32_t spp, uint32_t depths, uint32_t n1, uint32_t n2) {
+    hipLaunchKernelGGL(k_pack_tables, grid_for(spp * depths, 256), dim3(256), 0, s, tab, out, spp, depths, n1, n2);
+}
 void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
                    Pool pool, uint32_t* q, uint32_t n_pool) {
     hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool);

@@ -243,7 +243,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     const size_t QG = QCAP / 64 + 1, BG = BCAP / 64 + 1;
     size_t need = 0;
     auto acc = [&](size_t n, size_t sz) { need += (n * sz + 255) & ~(size_t)255; };
-    acc(CAP, 4 * 14); acc(CAP, 1); acc(CAP, 8); acc(CAP, 4); acc(CAP, 1); acc(CAP, 12); acc(CAP, 1);           // pool (each array separately below)
+    for (int i = 0; i < 5; i++) acc(CAP, 16);
+    acc(CAP, 4); acc(CAP, 1);                                                                      // pool records + termination
     need += 256 * 32;                                                                              // alignment slack for the separate pool arrays
     acc(QCAP, 4); acc(QCAP, 4); acc(BCAP, 4); acc(QCAP, 1); acc(BCAP, 1);                          // q, qn, bq, ent_obj, alive
     acc(QG * SCAN_NC_BIN, 1); acc(QG * SCAN_NC_BIN, 4); acc(QG, 4);                                // grp_cnt, grp_base, grp_tile
@@ -251,6 +252,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     acc(max_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                           // tiles, pgrp_tile
     for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
     acc(2, 4); acc(8, 4);
+    acc((size_t)(p->max_bounces + 1) * spp * ((8 + 12 + 8 * p->volume_marches) / 4), 16); // packed sample records
     const uint32_t NS = 4 + (ctx->world.has_scattering ? 4 * p->volume_marches : 0); // NEE samples per shading point
     const size_t JOBCAP = (size_t)NS * BCAP;
     if (JOBCAP >= ((size_t)1 << 32) || BCAP >= ((size_t)1 << 31)) return fail(ctx, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
@@ -266,13 +268,10 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     Arena& A = ctx->arena;
     A.off = 0;
     Pool pool;
-    pool.ox = A.take<float>(CAP); pool.oy = A.take<float>(CAP); pool.oz = A.take<float>(CAP);
-    pool.dx = A.take<float>(CAP); pool.dy = A.take<float>(CAP); pool.dz = A.take<float>(CAP); pool.time = A.take<float>(CAP);
-    pool.lr = A.take<float>(CAP); pool.lg = A.take<float>(CAP); pool.lb = A.take<float>(CAP);
-    pool.tr = A.take<float>(CAP); pool.tg = A.take<float>(CAP); pool.tb = A.take<float>(CAP);
-    pool.hit_t = A.take<float>(CAP); pool.hit_obj = A.take<uint8_t>(CAP);
-    pool.pix = A.take<uint32_t>(CAP); pool.samp = A.take<uint32_t>(CAP); pool.term_key = A.take<uint32_t>(CAP); pool.term_info = A.take<uint8_t>(CAP);
-    pool.n0x = A.take<float>(CAP); pool.n0y = A.take<float>(CAP); pool.n0z = A.take<float>(CAP); pool.obj0 = A.take<uint8_t>(CAP);
+    pool.geo0 = A.take<float4>(CAP); pool.geo1 = A.take<float4>(CAP); pool.col0 = A.take<float4>(CAP); pool.col1 = A.take<float4>(CAP);
+    pool.aov = A.take<float4>(CAP); pool.term_key = A.take<uint32_t>(CAP); pool.term_info = A.take<uint8_t>(CAP);
+    const uint32_t rec_stride = (8 + hs.n2) / 4, rec_depths = p->max_bounces + 1;
+    float4* d_rec = A.take<float4>((size_t)rec_depths * spp * rec_stride);
     uint32_t* q = A.take<uint32_t>(QCAP); uint32_t* qn = A.take<uint32_t>(QCAP); uint32_t* bq = A.take<uint32_t>(BCAP);
     uint8_t* ent_obj = A.take<uint8_t>(QCAP); uint8_t* alive = A.take<uint8_t>(BCAP);
     uint8_t* grp_cnt = A.take<uint8_t>(QG * SCAN_NC_BIN); uint32_t* grp_base = A.take<uint32_t>(QG * SCAN_NC_BIN); uint32_t* grp_tile = A.take<uint32_t>(QG);
@@ -294,7 +293,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     HIPCHK(hipEventRecord(ev_a, stream));
     HIPCHK(hipMemcpyAsync(ctx->d_scene, &hs, sizeof hs, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(ctx->d_evals, 0, 32, stream));
-    const Tables tab{d_s1, d_s2, d_fis};
+    const Tables tab{d_s1, d_s2, d_fis, d_rec, rec_stride};
+    launch_pack_tables(stream, tab, d_rec, spp, rec_depths, hs.n1, hs.n2);
     const bool count = ctx->counting;
 
     std::vector<DTile> h_tiles; std::vector<uint32_t> h_pgrp, h_tgb, h_tgc;
