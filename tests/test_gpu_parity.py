@@ -182,3 +182,81 @@ def test_errors_instead_of_panics(gpu_ctx):
     p.volume_marches = 1
     with pytest.raises(rayn_amd.film.RaynHipError):
         gpu_ctx.render_host(p, [np.zeros(8, np.float32)] * 4)
+
+
+# ---- the rest of the closed set (SURVEY.md section 8 f/N4): cameras, Lambertian, Box filter, odd scenes ----
+def _custom_world(kind, res):
+    import rayn_amd as R
+    from rayn_amd import setup as S
+    from rayn_amd.scene import _mul
+    cam_h, world = S.setup(res, volumes=(kind == "thinlens_volume"), sdf="mandelbox")
+    resf = (float(res[0]), float(res[1]))
+    origin = _mul(R.vec3(-0.45, 0.2, 2.0), 2.25)
+    if kind in ("thinlens", "thinlens_volume"):
+        world.cameras = R.CameraStore()
+        cam_h = world.cameras.add_camera(R.ThinLensCamera(resf, 50.0, 0.08, origin, R.vec3(0, 0, 0), R.vec3(0, 1, 0), R.vec3(0.2, 0.1, 0.9)))
+    elif kind == "ortho":
+        world.cameras = R.CameraStore()
+        cam_h = world.cameras.add_camera(R.OrthographicCamera(resf, 11.0 / 4.0, R.vec3(9.5, -3.5, 9.5), R.vec3(0.0, 0.8, 0.0), R.vec3(0, 1, 0)))
+    elif kind == "lambertian":
+        world.materials[1] = R.Lambertian(R.Srgb(0.6, 0.3, 0.2))
+    elif kind == "no_lights":
+        world.lights = []
+    elif kind == "spheres_only":
+        del world.hitables[1]
+    elif kind == "two_sdfs":
+        # a second TracedSDF (sphere SDF) after the MandelBox + one before it: exercises the multi-SDF march paths
+        world.hitables.insert(1, R.TracedSDF(R.SphereSDF(0.35), 1))
+        world.hitables.push(R.TracedSDF(R.MandelBox(6, R.BoxFold(1.0), R.SphereFold(0.5, 1.0), -2.0), 1))
+    elif kind == "lambert_sdf_sphere":
+        world.hitables[1] = R.TracedSDF(R.SphereSDF(1.0), world.materials.add_material(R.Lambertian(R.Srgb(0.5, 0.5, 0.5))))
+    else:
+        raise ValueError(kind)
+    return world.to_desc(cam_h)
+
+
+@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere"])
+def test_closed_set_parity(gpu_ctx, oracle, kind):
+    from rayn_amd import params as P
+    w, h, samples, bounces = 40, 32, 2, 4
+    wd = _custom_world(kind, (w, h))
+    p = P.frame_params(w, h, samples, bounces)
+    tabs = _tables(oracle, p)
+    ref, ctr = oracle.render(wd, p, tabs)
+    gpu_ctx.upload_world(wd)
+    out = gpu_ctx.render_host(p, tabs)
+    st = gpu_ctx.stats()
+    assert st["paths"] == ctr.paths and st["segments"] == ctr.segments
+    assert film_l2(out, ref) < L2_TOL
+    assert film_equal_bits(out, ref)
+    assert np.abs(ref["color"]).sum() + np.abs(ref["background"]).sum() > 0
+
+
+def test_box_filter_tables_parity(gpu_ctx, oracle):
+    import rayn_amd
+    wd, p = case("s0", 32, 32, 2, 2)
+    tabs = oracle.build_tables(8, 2, 2, 1, 32, 32, filter_kind=1, filter_radius=0.5)
+    mine = rayn_amd.build_tables(8, 2, 2, 1, 32, 32, rayn_amd.BoxFilter(0.5))
+    assert all(np.array_equal(a, b) for a, b in zip(tabs, mine))
+    ref, _ = oracle.render(wd, p, tabs)
+    gpu_ctx.upload_world(wd)
+    assert film_equal_bits(gpu_ctx.render_host(p, tabs), ref)
+
+
+def test_film_class_mirror(oracle):
+    """The host mirror with the reference's names: Film::new + render_frame_into + channel access."""
+    import rayn_amd as R
+    from rayn_amd import setup as S
+    W, H = 48, 32
+    cam, world = S.setup((W, H), volumes=True)
+    film = R.Film([R.ChannelKind.Color, R.ChannelKind.Alpha, R.ChannelKind.Background, R.ChannelKind.WorldNormal], (W, H))
+    integ = R.PathTracingIntegrator(max_bounces=3, volume_marches=2)
+    st = film.render_frame_into(world, cam, integ, R.BlackmanHarrisFilter(1.5), (16, 16), 1, None, 2)
+    p = R.frame_params(W, H, 2, 3)
+    ref, ctr = oracle.render(world.to_desc(cam), p, _tables(oracle, p))
+    assert st["paths"] == ctr.paths
+    got = {"color": film.channel(R.ChannelKind.Color), "alpha": film.channel(R.ChannelKind.Alpha),
+           "background": film.channel(R.ChannelKind.Background), "normal": film.channel(R.ChannelKind.WorldNormal)}
+    assert film_equal_bits(got, ref)
+    with pytest.raises(ValueError):
+        R.Film([R.ChannelKind.Color, R.ChannelKind.Color], (W, H))
