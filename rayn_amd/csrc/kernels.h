@@ -51,6 +51,9 @@ struct Tuning {
     uint32_t persistent_blocks = 256 * 8; // 256 CUs x 8 blocks of 4 waves = 32 waves per CU
     uint32_t refill_min_extend = 16;      // parked lanes before a wave runs epilogue + queue fetch
     uint32_t refill_min_shadow = 8;
+    uint32_t prefetch_min_extend = 32;    // fast path: lanes without a spare ray before the bulk queue fetch
+    uint32_t prefetch_min_shadow = 32;
+    bool fast_path = true;                // single-SDF specialisations k_extend1 / k_shadow1
 };
 
 // sample tables: the reference layout (src/sampler.rs:11-15) + a per-(depth, sample) packed copy built at
@@ -65,7 +68,7 @@ void launch_pack_tables(hipStream_t s, Tables tab, float4* out, uint32_t spp, ui
 void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
                    Pool pool, uint32_t* q, uint32_t n_pool);
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, uint32_t* head, unsigned long long* evals, const Tuning& tun);
+                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, uint32_t* head, unsigned long long* evals, const Tuning& tun);
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
                       const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
                       uint32_t* tile_valid);
@@ -74,7 +77,7 @@ void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_to
 void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
                         const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq);
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
-                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
+                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun);
 void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
                             const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn);

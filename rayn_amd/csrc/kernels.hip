@@ -182,6 +182,121 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path of k_extend for scenes with exactly ONE TracedSDF (every shipped scene).
+//  * The SDF parameters are wave-uniform and loaded once.
+//  * Sphere::hit returns an intrinsic value v (t1 if t1 > 1e-4 else t2) that is "valid" iff v <= t_max,
+//    and the fold (src/hitable.rs:177-198) accepts it iff v < closest-so-far.  The fold is therefore the
+//    first-wins minimum over [spheres before the SDF..., SDF march(t_max = closest of those), spheres
+//    after...]: the candidates of ALL spheres can be computed at fetch time, leaving two compares after
+//    the march.
+//  * Every lane keeps a prefetched NEXT ray (with its sphere candidates) in registers; a lane that ends
+//    its march stores the result and starts the next ray in the same loop trip.  The queue fetch runs in
+//    bulk when >= PREFETCH_MIN lanes have used up their spare ray, so lanes idle only at the very end.
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp, uint32_t depth, uint32_t ks, const uint32_t* __restrict__ q,
+                                                  uint32_t n_entries, Pool pool, uint8_t* __restrict__ ent_obj,
+                                                  uint32_t* __restrict__ head, uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
+    const DScene& sc = *scp;
+    const uint32_t lane = lane_id();
+    const Thr th = make_thr(sc, depth);
+    const uint32_t nh = sc.n_hitables, max_marches = sc.max_marches;
+    const DHitable h = sc.h[ks]; // uniform copy
+    const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+    // current ray
+    bool c_has = false, first = false, nan = false;
+    uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0, evals = 0;
+    f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
+    float c_pre = 0.0f, c_post = 0.0f, t = 0.0f;
+    // prefetched next ray
+    bool n_has = false;
+    uint32_t n_P = 0, n_ent = 0, n_ids = 0;
+    f3 n_o = f3{0, 0, 0}, n_d = f3{0, 0, 0};
+    float n_pre = 0.0f, n_post = 0.0f;
+    for (;;) {
+        const uint64_t lack = __ballot(!n_has);
+        const uint64_t idle = __ballot(!c_has && !n_has);
+        if (!exhausted && ((uint32_t)__popcll(lack) >= PREFETCH_MIN || (uint32_t)__popcll(idle) >= 4u)) {
+            for (;;) {
+                const uint64_t need = __ballot(!n_has);
+                if (need == 0) break;
+                if (cur == end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_entries) { exhausted = true; break; }
+                    cur = base;
+                    end = min(base + CHUNK, n_entries);
+                }
+                const uint32_t rank = mbcnt(need), avail = end - cur;
+                if (!n_has && rank < avail) {
+                    n_ent = cur + rank;
+                    n_P = q[n_ent];
+                    if (n_P == INVALID) ent_obj[n_ent] = (uint8_t)OBJ_NONE;
+                    else {
+                        const float4 g0 = pool.geo0[n_P];
+                        const float2 g1 = *(const float2*)(&pool.geo1[n_P].x);
+                        n_o = f3{g0.x, g0.y, g0.z};
+                        n_d = f3{g0.w, g1.x, g1.y};
+                        float closest = sc.t_max;
+                        uint32_t id = OBJ_NONE;
+                        for (uint32_t k = 0; k < ks; k++) { // spheres before the SDF: the true fold
+                            float ts = sphere_hit(sc.h[k], n_o, n_d, closest);
+                            if (ts < closest) { closest = ts; id = k; }
+                        }
+                        n_pre = closest;
+                        uint32_t idp = OBJ_NONE;
+                        for (uint32_t k = ks + 1; k < nh; k++) { // spheres after it: candidates (see header)
+                            float ts = sphere_hit(sc.h[k], n_o, n_d, closest);
+                            if (ts < closest) { closest = ts; idp = k; }
+                        }
+                        n_post = closest;
+                        n_ids = id | (idp << 8);
+                        n_has = true;
+                    }
+                }
+                cur += min((uint32_t)__popcll(need), avail);
+            }
+        }
+        if (!c_has && n_has) { // start the spare ray
+            c_has = true; n_has = false;
+            o = n_o; d = n_d; c_pre = n_pre; c_post = n_post; c_ids = n_ids; c_P = n_P; c_ent = n_ent;
+            first = true;
+        }
+        if (__ballot(c_has) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        if (c_has) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
+            const f3 p = first ? o : muladd3(d, t, o);
+            const float dist = sdf_dist<COUNT>(h, p, evals);
+            bool done;
+            if (first) { t = dist; nan = dist != dist; first = false; m = 0; done = max_marches == 0; }
+            else {
+                const bool hit = __builtin_fabsf(dist) < fmaxs(c0, c1 * thr_at(th, t));
+                const bool gt = t > c_pre;
+                done = hit || nan || gt;
+                if (!done) { t = t + dist; m++; done = m == max_marches; }
+            }
+            if (done) {
+                float closest = c_pre;
+                uint32_t id = c_ids & 0xFFu;
+                if (t < closest) { closest = t; id = ks; }
+                const uint32_t idp = c_ids >> 8;
+                if (idp != OBJ_NONE && c_post < closest) { closest = c_post; id = idp; }
+                pool.geo1[c_P].z = closest;
+                ((uint8_t*)&pool.geo1[c_P].w)[0] = (uint8_t)id; // low byte of the bits word = hit object
+                ent_obj[c_ent] = (uint8_t)id;
+                c_has = false;
+            }
+        }
+    }
+    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+}
+
 // per-group object histogram of the extend results (input of the bin scan)
 __global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8_t* __restrict__ ent_obj, uint32_t n_entries,
                                                      uint8_t* __restrict__ grp_cnt) {
@@ -670,6 +785,81 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
+// Fast path of k_shadow for scenes with exactly one TracedSDF: uniform SDF parameters, and a
+// prefetched NEXT segment per lane (see k_extend1).
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, const uint32_t* __restrict__ job_count,
+                                                  uint32_t* __restrict__ head, uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
+    const DScene& sc = *scp;
+    const uint32_t lane = lane_id();
+    const uint32_t n_jobs = *job_count, max_vis = sc.max_vis_marches;
+    const size_t jc = nee.jobcap;
+    const DHitable h = sc.h[ks];
+    const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+    bool c_has = false, first = false, nan = false, n_has = false;
+    uint32_t ref = 0, n_ref = 0, m = 0, evals = 0;
+    f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
+    float max_dist = 0.0f, n_max = 0.0f, t = 0.0f;
+    for (;;) {
+        const uint64_t lack = __ballot(!n_has);
+        const uint64_t idle = __ballot(!c_has && !n_has);
+        if (!exhausted && ((uint32_t)__popcll(lack) >= PREFETCH_MIN || (uint32_t)__popcll(idle) >= 4u)) {
+            for (;;) {
+                const uint64_t need = __ballot(!n_has);
+                if (need == 0) break;
+                if (cur == end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_jobs) { exhausted = true; break; }
+                    cur = base;
+                    end = min(base + CHUNK, n_jobs);
+                }
+                const uint32_t rank = mbcnt(need), avail = end - cur;
+                if (!n_has && rank < avail) {
+                    n_ref = nee.job_ref[cur + rank];
+                    n_start = f3{nee.job_geo[n_ref], nee.job_geo[jc + n_ref], nee.job_geo[2 * jc + n_ref]};
+                    const f3 e = f3{nee.job_geo[3 * jc + n_ref], nee.job_geo[4 * jc + n_ref], nee.job_geo[5 * jc + n_ref]};
+                    n_dir = e - n_start;
+                    n_max = mag(n_dir);
+                    n_dir = n_dir / n_max;
+                    n_has = true;
+                }
+                cur += min((uint32_t)__popcll(need), avail);
+            }
+        }
+        if (!c_has && n_has) {
+            c_has = true; n_has = false;
+            start = n_start; dir = n_dir; max_dist = n_max; ref = n_ref;
+            first = true;
+        }
+        if (__ballot(c_has) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        if (c_has) { // TracedSDF::occluded, src/sdf.rs:25-57
+            const f3 p = first ? start : muladd3(dir, t, start);
+            const float dist = sdf_dist<COUNT>(h, p, evals);
+            int res = -1; // -1 keep marching, 0 occluded, 1 visible
+            if (first) {
+                t = dist; nan = dist != dist; first = false; m = 0;
+                if (max_vis == 0) res = ((dist < 0.0001f) && !((dist > max_dist) || nan)) ? 0 : 1;
+                else if ((t > max_dist) || nan) res = 1;
+            } else {
+                if (__builtin_fabsf(dist) < fmaxs(c0, c1 * t)) res = 0;
+                else {
+                    t = t + dist; m++;
+                    if (m == max_vis || (t > max_dist) || nan) res = 1;
+                }
+            }
+            if (res >= 0) { nee.vis[ref] = (uint8_t)res; c_has = false; }
+        }
+    }
+    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+}
+
 __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__ scp, const uint32_t* __restrict__ bq, uint32_t n_slots,
                                                        Pool pool, Nee nee) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -887,10 +1077,13 @@ void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scr
     hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool);
 }
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, uint32_t* head, unsigned long long* evals, const Tuning& tun) {
+                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, uint32_t* head, unsigned long long* evals, const Tuning& tun) {
     (void)hipMemsetAsync(head, 0, 4, s);
     const dim3 grid(std::min<uint32_t>(tun.persistent_blocks, (n_entries + 255) / 256));
-    if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, tun.refill_min_extend, evals);
+    if (single_sdf >= 0 && tun.fast_path) {
+        if (count) hipLaunchKernelGGL(k_extend1<true>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, n_entries, pool, ent_obj, head, tun.prefetch_min_extend, evals);
+        else hipLaunchKernelGGL(k_extend1<false>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, n_entries, pool, ent_obj, head, tun.prefetch_min_extend, evals);
+    } else if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, tun.refill_min_extend, evals);
     else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, tun.refill_min_extend, evals);
     hipLaunchKernelGGL(k_group_hist, grid_for(n_entries, 256), dim3(256), 0, s, nclass, ent_obj, n_entries, grp_cnt);
 }
@@ -908,7 +1101,7 @@ void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const
     hipLaunchKernelGGL(k_bin_scatter, grid_for(n_entries, 256), dim3(256), 0, s, nclass, q, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
 }
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
-                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
+                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
     (void)hipMemsetAsync(counters + 1, 0, 8, s); // [1] shadow job count, [2] shadow queue head
     hooks.before(0);
@@ -919,7 +1112,10 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
         hooks.before(1);
         hipLaunchKernelGGL(k_shadow_list, grid_for(ns * n_slots, 256 * SCAN_ITEMS), dim3(256), 0, s, nee, ns, n_slots, counters + 1);
         const dim3 grid(std::min<uint32_t>(tun.persistent_blocks, (ns * n_slots + 255) / 256));
-        if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, tun.refill_min_shadow, evals + 2);
+        if (single_sdf >= 0 && tun.fast_path) {
+            if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, counters + 1, counters + 2, tun.prefetch_min_shadow, evals + 2);
+            else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, counters + 1, counters + 2, tun.prefetch_min_shadow, evals + 2);
+        } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, tun.refill_min_shadow, evals + 2);
         else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, tun.refill_min_shadow, evals + 2);
         hooks.after(1);
     }

@@ -293,6 +293,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     HIPCHK(hipEventRecord(ev_a, stream));
     HIPCHK(hipMemcpyAsync(ctx->d_scene, &hs, sizeof hs, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(ctx->d_evals, 0, 32, stream));
+    int single_sdf = -1; // index of the TracedSDF when the scene holds exactly one (fast-path kernels)
+    if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) single_sdf = (int)i;
     const Tables tab{d_s1, d_s2, d_fis, d_rec, rec_stride};
     launch_pack_tables(stream, tab, d_rec, spp, rec_depths, hs.n1, hs.n2);
     const bool count = ctx->counting;
@@ -323,7 +325,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         uint32_t n_entries = (uint32_t)n_pool;
         uint32_t* qcur = q; uint32_t* qnext = qn;
         for (uint32_t depth = 0; n_entries > 0; depth++) {
-            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, d_counters, ctx->d_evals, ctx->tun); }
+            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, single_sdf, d_counters, ctx->d_evals, ctx->tun); }
             ctx->stats.launches_extend++;
             {
                 Timed t(ctx, stream, PC_BIN);
@@ -349,7 +351,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
                 hooks.user = &hst;
                 hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->ctx, h->s, cls[i]); };
                 hooks.after_fn = [](void* u, int) { HookState* h = (HookState*)u; delete h->cur; h->cur = nullptr; };
-                launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks, ctx->tun);
+                launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, single_sdf, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks, ctx->tun);
             }
             ctx->stats.launches_shade++;
             ctx->stats.shaded_slots += n_slots;
@@ -411,6 +413,9 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     if (const char* e = getenv("RAYN_HIP_PROFILE")) ctx->profiling = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_REFILL_EXTEND")) ctx->tun.refill_min_extend = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("RAYN_HIP_REFILL_SHADOW")) ctx->tun.refill_min_shadow = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("RAYN_HIP_PREFETCH_EXTEND")) ctx->tun.prefetch_min_extend = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("RAYN_HIP_PREFETCH_SHADOW")) ctx->tun.prefetch_min_shadow = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("RAYN_HIP_FAST_PATH")) ctx->tun.fast_path = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_PERSISTENT_BLOCKS")) ctx->tun.persistent_blocks = (uint32_t)std::max(1, atoi(e));
     *out = ctx;
     return RAYN_OK;
