@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fma-policy", type=int, default=0, choices=[0, 1], help="0: unfused mul_add = rayn's default build (default); 1: fused = rayn built with +fma")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,6 +80,7 @@ def main():
     tabs = rayn_amd.build_tables(spp, bounces, p.volume_marches, p.frame, W, H)
     ctx = rayn_amd.Context(local_rank)
     ctx.upload_world(wd)
+    ctx.set_fma_policy(args.fma_policy)
     d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
     film = rayn_amd.film.alloc_device_film(W, H, device)
     gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device) if world > 1 else None
@@ -171,7 +173,7 @@ def main():
             "metric": "Mpath-samples/sec", "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "paths_per_step": paths_per_step, "tile": [p.tile_w, p.tile_h], "fma_policy": "unfused (reference default build)",
+            "config": {"workload": desc, "paths_per_step": paths_per_step, "tile": [p.tile_w, p.tile_h], "fma_policy": "unfused (reference default build)" if args.fma_policy == 0 else "fused (reference built with +fma)",
                        "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one RCCL gather to rank 0 per frame" if world > 1 else "")},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "kernel_ms": kernel_ms,
             "segments_per_step": stats["segments"] * world if world > 1 else stats["segments"],

@@ -25,7 +25,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define RAYN_HD __host__ __device__ inline
+#define RAYN_HD static __host__ __device__ inline
 #else
 #define RAYN_HD inline
 #endif

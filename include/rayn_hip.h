@@ -215,8 +215,11 @@ int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals);
 int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
 /* path-pool capacity per batch of tiles (default 2^27 paths: ~40 GB of HBM for a scene without volume). */
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
-/* 0: a*b+c unfused (reference default build), 1: fused (see include/rayn_detmath.h). */
+/* mul_add policy (include/rayn_detmath.h): 0 = unfused a*b+c, what rayn's default x86-64 build does (wide
+ * 0.4.6 without +fma) — the DEFAULT; 1 = fused, what rayn built with -C target-feature=+fma does.
+ * rayn_hip_fma_policy() returns the default policy of a new ctx. */
 int rayn_hip_fma_policy(void);
+int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy);
 /* sizeof() of the ABI structs as compiled: 0 world_desc, 1 frame_params, 2 stats, 3 hitable,
  * 4 material, 5 light, 6 camera — lets a binding verify its layout. */
 size_t rayn_hip_sizeof(int which);

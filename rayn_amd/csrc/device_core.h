@@ -11,7 +11,12 @@
 #include "device_scene.h"
 #include "kernels.h"
 
-namespace rayn {
+#ifndef RAYN_KNS
+#define RAYN_KNS rayn_p0
+#endif
+
+namespace RAYN_KNS {
+using namespace rayn;
 
 #define RD __device__ __forceinline__
 
@@ -431,4 +436,4 @@ RD uint32_t light_index(float s, uint32_t nl) {
     return i < nl ? i : nl - 1;
 }
 
-} // namespace rayn
+} // namespace RAYN_KNS

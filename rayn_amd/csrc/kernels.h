@@ -64,28 +64,59 @@ struct Tables {
     const float4* __restrict__ rec; uint32_t rec_stride; // float4 per record; record index = depth * spp + sample
 };
 
-void launch_pack_tables(hipStream_t s, Tables tab, float4* out, uint32_t spp, uint32_t depths, uint32_t n1, uint32_t n2);
-void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
-                   Pool pool, uint32_t* q, uint32_t n_pool);
-void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, uint32_t* head, unsigned long long* evals, const Tuning& tun);
-void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
-                      const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
-                      uint32_t* tile_valid);
-void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
-                        uint32_t* ogb, uint32_t* ogc, uint32_t* totals);
-void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
-                        const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq);
-void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
-                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
-                  unsigned long long* evals, ShadeHooks hooks, const Tuning& tun);
-void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
-                            const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn);
-void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
-                    float* out_color, float* out_alpha, float* out_background, float* out_normal);
-void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n);
-void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n);
-void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n);
-void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const float* b, float* out, uint32_t n);
+} // namespace rayn
 
+// The kernels are compiled twice (kernels.hip with RAYN_FMA_POLICY=0 -> namespace rayn_p0, =1 -> rayn_p1):
+// mul_add unfused (the reference's default x86-64 build) or fused (rayn built with +fma).
+#define RAYN_DECLARE_LAUNCHERS(NS)                                                                 \
+    namespace NS {                                                                                 \
+    using namespace rayn;                                                                          \
+    void launch_pack_tables(hipStream_t s, Tables tab, float4* out, uint32_t spp, uint32_t depths, uint32_t n1, uint32_t n2); \
+    void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile, \
+                       Pool pool, uint32_t* q, uint32_t n_pool);                                    \
+    void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool, \
+                       uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, uint32_t* head, unsigned long long* evals, const Tuning& tun); \
+    void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt, \
+                          const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total, \
+                          uint32_t* tile_valid);                                                    \
+    void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base, \
+                            uint32_t* ogb, uint32_t* ogc, uint32_t* totals);                        \
+    void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base, \
+                            const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq); \
+    void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq, \
+                      uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters, \
+                      unsigned long long* evals, ShadeHooks hooks, const Tuning& tun);              \
+    void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile, \
+                                const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn);     \
+    void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool, \
+                        float* out_color, float* out_alpha, float* out_background, float* out_normal); \
+    void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n); \
+    void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n); \
+    void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n); \
+    void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const float* b, float* out, uint32_t n); \
+    }
+RAYN_DECLARE_LAUNCHERS(rayn_p0)
+RAYN_DECLARE_LAUNCHERS(rayn_p1)
+
+namespace rayn {
+struct KernelSet {
+    decltype(&rayn_p0::launch_pack_tables) pack_tables;
+    decltype(&rayn_p0::launch_raygen) raygen;
+    decltype(&rayn_p0::launch_extend) extend;
+    decltype(&rayn_p0::launch_scan_tile) scan_tile;
+    decltype(&rayn_p0::launch_tile_prefix) tile_prefix;
+    decltype(&rayn_p0::launch_bin_scatter) bin_scatter;
+    decltype(&rayn_p0::launch_shade) shade;
+    decltype(&rayn_p0::launch_compact_scatter) compact_scatter;
+    decltype(&rayn_p0::launch_resolve) resolve;
+    decltype(&rayn_p0::launch_probe_dist) probe_dist;
+    decltype(&rayn_p0::launch_probe_closest) probe_closest;
+    decltype(&rayn_p0::launch_probe_occluded) probe_occluded;
+    decltype(&rayn_p0::launch_probe_detmath) probe_detmath;
+};
+#define RAYN_KERNEL_SET(NS) KernelSet{&NS::launch_pack_tables, &NS::launch_raygen, &NS::launch_extend, &NS::launch_scan_tile, &NS::launch_tile_prefix, &NS::launch_bin_scatter, &NS::launch_shade, &NS::launch_compact_scatter, &NS::launch_resolve, &NS::launch_probe_dist, &NS::launch_probe_closest, &NS::launch_probe_occluded, &NS::launch_probe_detmath}
+inline KernelSet kernel_set(int fma_policy) {
+    if (fma_policy) return RAYN_KERNEL_SET(rayn_p1);
+    return RAYN_KERNEL_SET(rayn_p0);
+}
 } // namespace rayn

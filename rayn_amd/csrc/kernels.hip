@@ -18,7 +18,7 @@
 #include "device_core.h"
 #include "kernels.h"
 
-namespace rayn {
+namespace RAYN_KNS {
 
 RD uint32_t lane_id() { return threadIdx.x & 63u; }
 // number of set bits of a 64-bit wave mask below this lane
@@ -1147,4 +1147,4 @@ void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const floa
     hipLaunchKernelGGL(k_probe_detmath, grid_for(n, 256), dim3(256), 0, s, op, a, b, out, n);
 }
 
-} // namespace rayn
+} // namespace RAYN_KNS

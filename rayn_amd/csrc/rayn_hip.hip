@@ -55,6 +55,7 @@ struct rayn_ctx {
     bool profiling = false, counting = false;
     size_t batch_paths = (size_t)1 << 27;
     Tuning tun;
+    int fma_policy = 0; // 0: mul_add unfused (reference default build), 1: fused
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
 };
@@ -293,10 +294,11 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     HIPCHK(hipEventRecord(ev_a, stream));
     HIPCHK(hipMemcpyAsync(ctx->d_scene, &hs, sizeof hs, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(ctx->d_evals, 0, 32, stream));
+    const KernelSet K = kernel_set(ctx->fma_policy);
     int single_sdf = -1; // index of the TracedSDF when the scene holds exactly one (fast-path kernels)
     if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) single_sdf = (int)i;
     const Tables tab{d_s1, d_s2, d_fis, d_rec, rec_stride};
-    launch_pack_tables(stream, tab, d_rec, spp, rec_depths, hs.n1, hs.n2);
+    K.pack_tables(stream, tab, d_rec, spp, rec_depths, hs.n1, hs.n2);
     const bool count = ctx->counting;
 
     std::vector<DTile> h_tiles; std::vector<uint32_t> h_pgrp, h_tgb, h_tgc;
@@ -321,16 +323,16 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         HIPCHK(hipMemcpyAsync(tgcA, h_tgc.data(), nt * 4, hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
 
-        { Timed t(ctx, stream, PC_RAYGEN); launch_raygen(stream, ctx->d_scene, tab, d_scr, d_tiles, pgrp_tile, pool, q, (uint32_t)n_pool); }
+        { Timed t(ctx, stream, PC_RAYGEN); K.raygen(stream, ctx->d_scene, tab, d_scr, d_tiles, pgrp_tile, pool, q, (uint32_t)n_pool); }
         uint32_t n_entries = (uint32_t)n_pool;
         uint32_t* qcur = q; uint32_t* qnext = qn;
         for (uint32_t depth = 0; n_entries > 0; depth++) {
-            { Timed t(ctx, stream, PC_EXTEND); launch_extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, single_sdf, d_counters, ctx->d_evals, ctx->tun); }
+            { Timed t(ctx, stream, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, single_sdf, d_counters, ctx->d_evals, ctx->tun); }
             ctx->stats.launches_extend++;
             {
                 Timed t(ctx, stream, PC_BIN);
-                launch_scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid);
-                launch_tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_totals);
+                K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_totals);
             }
             HIPCHK(hipMemcpyAsync(ctx->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
@@ -341,7 +343,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
             {
                 Timed t(ctx, stream, PC_BIN);
                 HIPCHK(hipMemsetAsync(bq, 0xFF, (size_t)n_slots * 4, stream));
-                launch_bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
+                K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
             }
             ctx->stats.queue_bytes += (uint64_t)n_entries * (4 + 1 + 4) + (uint64_t)n_slots * 4;
             {
@@ -351,14 +353,14 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
                 hooks.user = &hst;
                 hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->ctx, h->s, cls[i]); };
                 hooks.after_fn = [](void* u, int) { HookState* h = (HookState*)u; delete h->cur; h->cur = nullptr; };
-                launch_shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, single_sdf, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks, ctx->tun);
+                K.shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, single_sdf, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks, ctx->tun);
             }
             ctx->stats.launches_shade++;
             ctx->stats.shaded_slots += n_slots;
             {
                 Timed t(ctx, stream, PC_COMPACT);
-                launch_scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid);
-                launch_tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_totals);
+                K.scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_totals);
             }
             HIPCHK(hipMemcpyAsync(ctx->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
@@ -368,13 +370,13 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
             {
                 Timed t(ctx, stream, PC_COMPACT);
                 HIPCHK(hipMemsetAsync(qnext, 0xFF, (size_t)n_next * 4, stream));
-                launch_compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, n_slots, qnext);
+                K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, n_slots, qnext);
             }
             ctx->stats.queue_bytes += (uint64_t)n_slots * (4 + 1) + (uint64_t)n_next * 4;
             std::swap(qcur, qnext);
             n_entries = n_next;
         }
-        { Timed t(ctx, stream, PC_RESOLVE); launch_resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, d_color, d_alpha, d_bg, d_normal); }
+        { Timed t(ctx, stream, PC_RESOLVE); K.resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, d_color, d_alpha, d_bg, d_normal); }
     }
     HIPCHK(hipEventRecord(ev_b, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -522,10 +524,11 @@ static int probe_common(rayn_ctx* ctx, const rayn_frame_params* p) {
 int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t hitable_index, const float* pts, float* out, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
+    const KernelSet K = kernel_set(ctx->fma_policy);
     float *d_in = nullptr, *d_out = nullptr;
     HIPCHK(hipMalloc((void**)&d_in, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
     HIPCHK(hipMemcpy(d_in, pts, (size_t)n * 12, hipMemcpyHostToDevice));
-    launch_probe_dist(ctx->stream, ctx->d_scene, hitable_index, d_in, d_out, n);
+    K.probe_dist(ctx->stream, ctx->d_scene, hitable_index, d_in, d_out, n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
     hipFree(d_in); hipFree(d_out);
@@ -535,11 +538,12 @@ int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32
                                uint32_t* out_obj, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
+    const KernelSet K = kernel_set(ctx->fma_policy);
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; uint32_t* d_obj = nullptr;
     HIPCHK(hipMalloc((void**)&d_o, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_d, (size_t)n * 12));
     HIPCHK(hipMalloc((void**)&d_t, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_obj, (size_t)n * 4));
     HIPCHK(hipMemcpy(d_o, org, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice));
-    launch_probe_closest(ctx->stream, ctx->d_scene, depth, d_o, d_d, d_t, d_obj, n);
+    K.probe_closest(ctx->stream, ctx->d_scene, depth, d_o, d_d, d_t, d_obj, n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_obj, d_obj, (size_t)n * 4, hipMemcpyDeviceToHost));
     hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_obj);
@@ -548,10 +552,11 @@ int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32
 int rayn_hip_probe_occluded(rayn_ctx* ctx, const rayn_frame_params* p, const float* start, const float* end, float* out, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
+    const KernelSet K = kernel_set(ctx->fma_policy);
     float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
     HIPCHK(hipMalloc((void**)&d_a, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
     HIPCHK(hipMemcpy(d_a, start, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, end, (size_t)n * 12, hipMemcpyHostToDevice));
-    launch_probe_occluded(ctx->stream, ctx->d_scene, d_a, d_b, d_out, n);
+    K.probe_occluded(ctx->stream, ctx->d_scene, d_a, d_b, d_out, n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
     hipFree(d_a); hipFree(d_b); hipFree(d_out);
@@ -559,17 +564,23 @@ int rayn_hip_probe_occluded(rayn_ctx* ctx, const rayn_frame_params* p, const flo
 }
 int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const float* b, float* out, uint32_t n) {
     if (!ctx) return RAYN_ERR_INVALID_ARG;
+    const KernelSet K = kernel_set(ctx->fma_policy);
     HIPCHK(hipSetDevice(ctx->device));
     float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
     HIPCHK(hipMalloc((void**)&d_a, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
     HIPCHK(hipMemcpy(d_a, a, (size_t)n * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, b, (size_t)n * 4, hipMemcpyHostToDevice));
-    launch_probe_detmath(ctx->stream, op, d_a, d_b, d_out, n);
+    K.probe_detmath(ctx->stream, op, d_a, d_b, d_out, n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
     hipFree(d_a); hipFree(d_b); hipFree(d_out);
     return RAYN_OK;
 }
-int rayn_hip_fma_policy(void) { return RAYN_FMA_POLICY; }
+int rayn_hip_fma_policy(void) { return 0; }
+int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy) {
+    if (!ctx || (policy != 0 && policy != 1)) return RAYN_ERR_INVALID_ARG;
+    ctx->fma_policy = policy;
+    return RAYN_OK;
+}
 size_t rayn_hip_sizeof(int which) {
     switch (which) {
     case 0: return sizeof(rayn_world_desc);

@@ -66,6 +66,10 @@ class Context:
     def set_profiling(self, timing=True, count_evals=False):
         self._chk(self._L.rayn_hip_set_profiling(self.h, int(timing), int(count_evals)))
 
+    def set_fma_policy(self, policy):
+        """0 = unfused mul_add (reference default build, the default), 1 = fused (rayn built with +fma)."""
+        self._chk(self._L.rayn_hip_set_fma_policy(self.h, int(policy)))
+
     def set_batch_paths(self, n):
         self._chk(self._L.rayn_hip_set_batch_paths(self.h, int(n)))
 

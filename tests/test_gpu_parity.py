@@ -260,3 +260,21 @@ def test_film_class_mirror(oracle):
     assert film_equal_bits(got, ref)
     with pytest.raises(ValueError):
         R.Film([R.ChannelKind.Color, R.ChannelKind.Color], (W, H))
+
+
+@pytest.mark.parametrize("name,w,h,samples,bounces", [("s1", 48, 32, 2, 4), ("s2", 32, 24, 1, 3), ("s0", 48, 48, 2, 3)])
+def test_fma_policy_variant(gpu_ctx, oracle, name, w, h, samples, bounces):
+    """mul_add policy 1 (rayn built with +fma): the fused kernels against the fused oracle build, and they
+    must differ from the default build (otherwise the switch does nothing)."""
+    wd, p = case(name, w, h, samples, bounces)
+    tabs = _tables(oracle, p)
+    ref1, _ = oracle.render(wd, p, tabs, fma=True)
+    ref0, _ = oracle.render(wd, p, tabs, fma=False)
+    gpu_ctx.upload_world(wd)
+    gpu_ctx.set_fma_policy(1)
+    try:
+        out1 = gpu_ctx.render_host(p, tabs)
+    finally:
+        gpu_ctx.set_fma_policy(0)
+    assert film_equal_bits(out1, ref1)
+    assert not film_equal_bits(ref1, ref0)
