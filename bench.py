@@ -139,12 +139,26 @@ def main():
                                               "tflops": round(FLOP_PER_DIST * v[1] / max(v[0], 1e-9) / 1e9, 3)} for k, v in classes.items()},
                     "note": "march kernels are FP32-VALU bound (SURVEY.md F6): achieved = 404 flop x SDF evals / kernel time; "
                             "peak = MI355X FP32 vector peak (= dense f32-input MFMA peak)"}
-        qms = st["ms_raygen"] + st["ms_bin"] + st["ms_compact"] + st["ms_resolve"] + st["ms_finish"]
-        qbytes = st["queue_bytes"] + 68 * st["paths"] + 40 * W * H / world + 24 * st["paths"]  # scatter/compact + ray-gen + film + resolve reads
-        ach = qbytes / (qms * 1e-3) / 1e9 if qms > 0 else 0.0
-        roofline_hbm = {"kernels": "k_raygen+k_scan_tile+k_tile_prefix+k_bin_scatter+k_shade_finish+k_compact_scatter+k_resolve", "bound": "hbm",
-                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                        "ms": round(qms, 3)}
+        # HBM-bound queue kernels: algorithmic bytes / HIP-event time per kernel class
+        npool = st["paths"]
+        qk = {
+            "k_raygen": (st["ms_raygen"], 85.0 * npool),                      # 5 records of 16 B + term_info + queue entry per path
+            "bin(k_group_hist+k_scan_tile+k_tile_prefix+memset+k_bin_scatter)": (st["ms_bin"], st["queue_bytes_bin"]),
+            "compact(k_scan_tile+k_tile_prefix+memset+k_compact_scatter)": (st["ms_compact"], st["queue_bytes_compact"]),
+            "k_resolve": (st["ms_resolve"], 37.0 * npool + 40.0 * W * H / world),  # col0 + aov + termination record per path, film out
+        }
+        roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": {}}
+        for name, (ms_k, nbytes) in qk.items():
+            ach = nbytes / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
+            roofline_hbm["kernels"][name] = {"ms": round(ms_k, 3), "algorithmic_bytes": nbytes, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+        pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_{args.workload}.json")
+        if os.path.exists(pmc_path) and world == 1 and args.fma_policy == 0:
+            pmc = json.load(open(pmc_path))["kernels"]
+            dk = {"extend": "k_extend1", "shadow": "k_shadow1", "shade_setup": "k_shade_setup"}[dom]
+            if dk in pmc and "hbm_bytes_per_launch" in pmc[dk]:
+                roofline["traffic"] = pmc[dk]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = f"profiles/r01_pmc_hbm_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
+            roofline_hbm["pmc_traffic"] = {k: {"hbm_bytes": v["hbm_bytes"], "GBps": round(v.get("hbm_GBps", 0.0), 1)} for k, v in pmc.items()}
         kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_shadow", "ms_finish", "ms_compact", "ms_resolve", "ms_total")}
     else:
         kernel_ms = None

@@ -151,8 +151,9 @@ typedef struct {
     double ms_total;         /* HIP-event time of the whole render on the ctx stream */
     double ms_raygen, ms_extend, ms_bin, ms_shade, ms_compact, ms_resolve; /* ms_shade = k_shade_setup */
     uint64_t launches_extend, launches_shade;
-    uint64_t queue_bytes;    /* algorithmic HBM bytes moved by the queue kernels */
+    uint64_t queue_bytes_bin;     /* algorithmic HBM bytes of the bin stage */
     double ms_shadow, ms_finish; /* k_shadow, k_shade_finish */
+    uint64_t queue_bytes_compact; /* algorithmic HBM bytes of the repack stage */
 } rayn_stats;
 
 typedef struct rayn_ctx rayn_ctx;

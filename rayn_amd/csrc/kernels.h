@@ -33,7 +33,7 @@ struct Nee {
     uint8_t* flags; // [cap]      bit0 alive, bit1 surface NEE, bit2 volume NEE
     size_t cap;
     uint32_t* job_ref; // [jobcap] dense list of pending [sample*cap + slot] indices (k_shadow_list)
-    float* job_geo;    // [6][jobcap] pending shadow segments: start xyz, end xyz at [sample*cap + slot]
+    float4* job_geo;   // [jobcap][2] pending shadow segments (start.xyz, end.x | end.yz, -, -) at [sample*cap + slot]
     size_t jobcap;
 };
 

@@ -526,12 +526,12 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     bool is_alive = false;
     uint32_t evals = 0, flags = 0;
     // shadow jobs live IN PLACE: vis[s][slot] = 2 marks "SDF march pending" and the segment is parked at
-    // job_geo[..][s*cap + slot]; k_shadow scans all (sample, slot) pairs.  (A compacted job list would need
+    // job_geo[2*(s*cap + slot)..]; k_shadow_list collects the pending (sample, slot) pairs.  (A compacted job list would need
     // one atomic per wave per sample on a single counter - that alone cost 0.5 s per frame.)
     auto park_job = [&](uint32_t s, f3 a, f3 b) {
-        const size_t idx = s * cap + j, jc = nee.jobcap;
-        nee.job_geo[idx] = a.x; nee.job_geo[jc + idx] = a.y; nee.job_geo[2 * jc + idx] = a.z;
-        nee.job_geo[3 * jc + idx] = b.x; nee.job_geo[4 * jc + idx] = b.y; nee.job_geo[5 * jc + idx] = b.z;
+        const size_t idx = s * cap + j; // 32 contiguous bytes per segment: one or two HBM sectors per fetch
+        nee.job_geo[2 * idx] = make_float4(a.x, a.y, a.z, b.x);
+        nee.job_geo[2 * idx + 1] = make_float4(b.y, b.z, 0.0f, 0.0f);
     };
     // analytic spheres of test_occluded (every factor is exactly 0 or 1 -> order independent)
     auto spheres_visible = [&](f3 a, f3 b) {
@@ -718,7 +718,6 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
     const uint32_t n_jobs = *job_count, nh = sc.n_hitables;
-    const size_t jc = nee.jobcap;
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
@@ -748,8 +747,9 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
                 const uint32_t rank = mbcnt(need), avail = end - cur;
                 if (!has && rank < avail) {
                     ref = nee.job_ref[cur + rank]; // [sample][slot]
-                    start = f3{nee.job_geo[ref], nee.job_geo[jc + ref], nee.job_geo[2 * jc + ref]};
-                    const f3 e = f3{nee.job_geo[3 * jc + ref], nee.job_geo[4 * jc + ref], nee.job_geo[5 * jc + ref]};
+                    const float4 ja = nee.job_geo[2 * (size_t)ref], jb = nee.job_geo[2 * (size_t)ref + 1];
+                    start = f3{ja.x, ja.y, ja.z};
+                    const f3 e = f3{ja.w, jb.x, jb.y};
                     dir = e - start;
                     max_dist = mag(dir);
                     dir = dir / max_dist;
@@ -793,7 +793,6 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
     const uint32_t n_jobs = *job_count, max_vis = sc.max_vis_marches;
-    const size_t jc = nee.jobcap;
     const DHitable h = sc.h[ks];
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
@@ -820,8 +819,9 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                 const uint32_t rank = mbcnt(need), avail = end - cur;
                 if (!n_has && rank < avail) {
                     n_ref = nee.job_ref[cur + rank];
-                    n_start = f3{nee.job_geo[n_ref], nee.job_geo[jc + n_ref], nee.job_geo[2 * jc + n_ref]};
-                    const f3 e = f3{nee.job_geo[3 * jc + n_ref], nee.job_geo[4 * jc + n_ref], nee.job_geo[5 * jc + n_ref]};
+                    const float4 ja = nee.job_geo[2 * (size_t)n_ref], jb = nee.job_geo[2 * (size_t)n_ref + 1];
+                    n_start = f3{ja.x, ja.y, ja.z};
+                    const f3 e = f3{ja.w, jb.x, jb.y};
                     n_dir = e - n_start;
                     n_max = mag(n_dir);
                     n_dir = n_dir / n_max;

@@ -258,7 +258,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     const size_t JOBCAP = (size_t)NS * BCAP;
     if (JOBCAP >= ((size_t)1 << 32) || BCAP >= ((size_t)1 << 31)) return fail(ctx, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
     acc(NS * 3 * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);
-    acc(JOBCAP, 4); acc(6 * JOBCAP, 4);
+    acc(JOBCAP, 4); acc(2 * JOBCAP, 16);
     if (need > ctx->arena.cap) {
         if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
         ctx->arena.base = nullptr; ctx->arena.cap = 0;
@@ -287,7 +287,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     nee.cap = BCAP; nee.jobcap = JOBCAP;
     nee.x = A.take<float>(NS * 3 * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
     nee.vis = A.take<uint8_t>(NS * BCAP); nee.T = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
-    nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float>(6 * JOBCAP);
+    nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float4>(2 * JOBCAP);
     if (A.off > A.cap) return fail(ctx, RAYN_ERR_OOM, "internal: arena under-sized");
 
     hipEvent_t ev_a = get_event(ctx), ev_b = get_event(ctx);
@@ -345,7 +345,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
                 HIPCHK(hipMemsetAsync(bq, 0xFF, (size_t)n_slots * 4, stream));
                 K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
             }
-            ctx->stats.queue_bytes += (uint64_t)n_entries * (4 + 1 + 4) + (uint64_t)n_slots * 4;
+            // group_hist reads 1 B/entry; scatter reads q (4) + ent_obj (1), writes bq (4); memset writes bq (4); scans ~17 B/group
+            ctx->stats.queue_bytes_bin += (uint64_t)n_entries * (1 + 4 + 1) + (uint64_t)n_slots * (4 + 4) + (uint64_t)(n_entries / 64) * 85;
             {
                 static const int cls[3] = {PC_SHADE, PC_SHADOW, PC_FINISH};
                 struct HookState { rayn_ctx* ctx; hipStream_t s; Timed* cur; } hst{ctx, stream, nullptr};
@@ -372,7 +373,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
                 HIPCHK(hipMemsetAsync(qnext, 0xFF, (size_t)n_next * 4, stream));
                 K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, n_slots, qnext);
             }
-            ctx->stats.queue_bytes += (uint64_t)n_slots * (4 + 1) + (uint64_t)n_next * 4;
+            // compact_scatter reads bq (4) + alive (1), writes q' (4); memset writes q' (4); scans ~9 B/group
+            ctx->stats.queue_bytes_compact += (uint64_t)n_slots * (4 + 1) + (uint64_t)n_next * (4 + 4) + (uint64_t)(n_slots / 64) * 9;
             std::swap(qcur, qnext);
             n_entries = n_next;
         }
