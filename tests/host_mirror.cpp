@@ -1,0 +1,39 @@
+// Test driver for include/rayn_host.hpp (the C++ host mirror).
+//   host_mirror desc W H volumes out.bin                -> raw rayn_world_desc of setup::setup()   (no GPU needed)
+//   host_mirror render W H SAMPLES BOUNCES volumes out.bin -> film: color(3n) alpha(n) background(3n) normal(3n) floats
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../include/rayn_host.hpp"
+
+int main(int argc, char** argv) {
+    using namespace rayn;
+    if (argc < 6) return 2;
+    const uint32_t W = atoi(argv[2]), H = atoi(argv[3]);
+    if (!strcmp(argv[1], "desc")) {
+        auto [cam, world] = setup::setup(Extent2u(W, H), atoi(argv[4]) != 0);
+        rayn_world_desc d = world.to_desc(cam);
+        FILE* f = fopen(argv[5], "wb");
+        fwrite(&d, sizeof d, 1, f);
+        fclose(f);
+        return 0;
+    }
+    if (argc < 8) return 2;
+    auto [cam, world] = setup::setup(Extent2u(W, H), atoi(argv[6]) != 0);
+    try {
+        Film dup({ChannelKind::Color, ChannelKind::Color}, Extent2u(W, H));
+        return 3; // must have thrown (Film::new returns Err for duplicate kinds)
+    } catch (const std::invalid_argument&) {}
+    Film film({ChannelKind::Color, ChannelKind::Alpha, ChannelKind::Background, ChannelKind::WorldNormal}, Extent2u(W, H));
+    PathTracingIntegrator integ{(size_t)atoi(argv[5]), 2};
+    const float t0 = 1.0f * (1.0f / 24.0f);
+    film.render_frame_into(world, cam, integ, BlackmanHarrisFilter::new_(1.5f), Extent2u(16, 16), 1, {t0, t0 + 1.0f / 24.0f}, (size_t)atoi(argv[4]));
+    FILE* f = fopen(argv[7], "wb");
+    fwrite(film.color.data(), 4, film.color.size(), f);
+    fwrite(film.alpha.data(), 4, film.alpha.size(), f);
+    fwrite(film.background.data(), 4, film.background.size(), f);
+    fwrite(film.world_normal.data(), 4, film.world_normal.size(), f);
+    fclose(f);
+    return 0;
+}
