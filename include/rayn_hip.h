@@ -108,6 +108,13 @@ typedef struct {
     rayn_vec3 origin, at, up;
     float aperture;     /* thin lens */
     rayn_vec3 focus;    /* thin lens */
+    /* Time-sequenced parameters (src/animation.rs): the reference lets origin/at/up/focus be closures
+     * Fn(f32) -> Vec3.  Closures cannot cross the ABI; the closed set offers the linear closure
+     * |t| base + vel * t per parameter (bit 0 origin, 1 at, 2 up, 3 focus of 'animated').  As in the
+     * reference (src/animation.rs:62-68) a closure is evaluated at the time of LANE 0 of the ray-gen
+     * packet (sample 4*floor(s/4) of the pixel) for all four lanes. */
+    uint32_t animated;
+    rayn_vec3 origin_vel, at_vel, up_vel, focus_vel;
 } rayn_camera;
 
 /* ---- World (src/world.rs:7-13) + VolumeParams (src/volume.rs:1-5) ------------------------- */

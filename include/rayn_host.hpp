@@ -110,12 +110,20 @@ class HitableStore {
 // ---- lights, cameras, volume --------------------------------------------------------------------
 struct SphereLight { Vec3 pos; float rad; Srgb emission; static SphereLight new_(Vec3 p, float r, Srgb e) { return SphereLight{p, r, e}; } };
 
-struct PinholeCamera { Vec2 resolution; float vfov; Vec3 origin, at, up;
-                       static PinholeCamera new_(Vec2 res, float vfov, Vec3 o, Vec3 a, Vec3 u) { return PinholeCamera{res, vfov, o, a, u}; } };
-struct ThinLensCamera { Vec2 resolution; float vfov, aperture; Vec3 origin, at, up, focus;
-                        static ThinLensCamera new_(Vec2 res, float vfov, float ap, Vec3 o, Vec3 a, Vec3 u, Vec3 f) { return ThinLensCamera{res, vfov, ap, o, a, u, f}; } };
-struct OrthographicCamera { Vec2 resolution; float vertical_size; Vec3 origin, at, up;
-                            static OrthographicCamera new_(Vec2 res, float vs, Vec3 o, Vec3 a, Vec3 u) { return OrthographicCamera{res, vs, o, a, u}; } };
+// A time-sequenced Vec3 (src/animation.rs): a constant, or the closure `move |t| base + vel * t`
+struct Sequenced3 {
+    Vec3 base, vel; bool animated = false;
+    Sequenced3() = default;
+    Sequenced3(Vec3 constant) : base(constant) {}
+    static Sequenced3 linear(Vec3 base, Vec3 vel) { Sequenced3 s; s.base = base; s.vel = vel; s.animated = true; return s; }
+};
+
+struct PinholeCamera { Vec2 resolution; float vfov; Sequenced3 origin, at, up;
+                       static PinholeCamera new_(Vec2 res, float vfov, Sequenced3 o, Sequenced3 a, Sequenced3 u) { return PinholeCamera{res, vfov, o, a, u}; } };
+struct ThinLensCamera { Vec2 resolution; float vfov, aperture; Sequenced3 origin, at, up, focus;
+                        static ThinLensCamera new_(Vec2 res, float vfov, float ap, Sequenced3 o, Sequenced3 a, Sequenced3 u, Sequenced3 f) { return ThinLensCamera{res, vfov, ap, o, a, u, f}; } };
+struct OrthographicCamera { Vec2 resolution; float vertical_size; Sequenced3 origin, at, up;
+                            static OrthographicCamera new_(Vec2 res, float vs, Sequenced3 o, Sequenced3 a, Sequenced3 u) { return OrthographicCamera{res, vs, o, a, u}; } };
 using Camera = std::variant<PinholeCamera, ThinLensCamera, OrthographicCamera>;
 class CameraStore {
   public:
@@ -166,16 +174,17 @@ struct World { // src/world.rs:7-13
         }
         rayn_camera& c = d.camera;
         const Camera& cam = cameras.get(camera);
+        auto put = [&c](rayn_vec3& dst, rayn_vec3& vel, uint32_t bit, const Sequenced3& s) { dst = s.base.pod(); if (s.animated) { vel = s.vel.pod(); c.animated |= 1u << bit; } };
         if (const PinholeCamera* p = std::get_if<PinholeCamera>(&cam)) {
             c.kind = RAYN_CAM_PINHOLE; c.res_w = p->resolution.x; c.res_h = p->resolution.y; c.vfov_or_size = p->vfov;
-            c.origin = p->origin.pod(); c.at = p->at.pod(); c.up = p->up.pod();
+            put(c.origin, c.origin_vel, 0, p->origin); put(c.at, c.at_vel, 1, p->at); put(c.up, c.up_vel, 2, p->up);
         } else if (const ThinLensCamera* t = std::get_if<ThinLensCamera>(&cam)) {
             c.kind = RAYN_CAM_THIN_LENS; c.res_w = t->resolution.x; c.res_h = t->resolution.y; c.vfov_or_size = t->vfov; c.aperture = t->aperture;
-            c.origin = t->origin.pod(); c.at = t->at.pod(); c.up = t->up.pod(); c.focus = t->focus.pod();
+            put(c.origin, c.origin_vel, 0, t->origin); put(c.at, c.at_vel, 1, t->at); put(c.up, c.up_vel, 2, t->up); put(c.focus, c.focus_vel, 3, t->focus);
         } else {
             const OrthographicCamera& o = std::get<OrthographicCamera>(cam);
             c.kind = RAYN_CAM_ORTHOGRAPHIC; c.res_w = o.resolution.x; c.res_h = o.resolution.y; c.vfov_or_size = o.vertical_size;
-            c.origin = o.origin.pod(); c.at = o.at.pod(); c.up = o.up.pod();
+            put(c.origin, c.origin_vel, 0, o.origin); put(c.at, c.at_vel, 1, o.at); put(c.up, c.up_vel, 2, o.up);
         }
         if (volume_params.coeff_scattering) { d.has_scattering = 1; d.coeff_scattering = *volume_params.coeff_scattering; }
         if (volume_params.coeff_extinction) { d.has_extinction = 1; d.coeff_extinction = *volume_params.coeff_extinction; }

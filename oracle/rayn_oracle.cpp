@@ -525,8 +525,18 @@ struct SphereLight {
 struct Camera {
     uint32_t kind; W2 half_size; W2 full_size; F4 half_pixel_size;
     V3 origin, at, up, focus; float aperture;
+    uint32_t animated; V3 origin_vel, at_vel, up_vel, focus_vel;
+    /* WSequenced::sample_at: constants clone themselves (src/animation.rs:27-36); the closure `|t| base + vel*t`
+     * is evaluated at lane 0's time for all four lanes (src/animation.rs:62-68) */
+    W3 sample_at(V3 base, V3 vel, bool anim, F4 time) const {
+        if (!anim) return W3::splat(base);
+        float t = time.v[0];
+        return W3::splat(V3{base.x + vel.x * t, base.y + vel.y * t, base.z + vel.z * t});
+    }
     explicit Camera(const rayn_camera& c) {
-        kind = c.kind;
+        kind = c.kind; animated = c.animated;
+        origin_vel = V3{c.origin_vel.x, c.origin_vel.y, c.origin_vel.z}; at_vel = V3{c.at_vel.x, c.at_vel.y, c.at_vel.z};
+        up_vel = V3{c.up_vel.x, c.up_vel.y, c.up_vel.z}; focus_vel = V3{c.focus_vel.x, c.focus_vel.y, c.focus_vel.z};
         origin = V3{c.origin.x, c.origin.y, c.origin.z}; at = V3{c.at.x, c.at.y, c.at.z};
         up = V3{c.up.x, c.up.y, c.up.z}; focus = V3{c.focus.x, c.focus.y, c.focus.z}; aperture = c.aperture;
         if (kind == RAYN_CAM_ORTHOGRAPHIC) { /* :228-240 */
@@ -551,7 +561,7 @@ struct Camera {
         return r;
     }
     WRay get_rays(float scramble, const size_t nums[4], uint32_t tcx, uint32_t tcy, W2 uv, F4 time, const F4* samples) const {
-        W3 o = W3::splat(origin), a = W3::splat(at), u = W3::splat(up);
+        W3 o = sample_at(origin, origin_vel, animated & 1u, time), a = sample_at(at, at_vel, animated & 2u, time), u = sample_at(up, up_vel, animated & 4u, time);
         if (kind == RAYN_CAM_PINHOLE) { /* :81-114 */
             W3 basis_w = normalized(o - a);
             W3 basis_u = normalized(cross(u, basis_w));
@@ -561,7 +571,7 @@ struct Camera {
             W3 verti = basis_v * half_size.y * F4(2.0f) * uv.y;
             return make(o, normalized(lower_left + horiz + verti - o), time, tcx, tcy, scramble, nums);
         } else if (kind == RAYN_CAM_THIN_LENS) { /* :168-208 */
-            W3 f = W3::splat(focus);
+            W3 f = sample_at(focus, focus_vel, animated & 8u, time);
             F4 focus_dist = mag(f - o);
             F4 ap(aperture);
             W3 basis_w = normalized(o - a);

@@ -34,7 +34,8 @@ class Light(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("res_w", C.c_float), ("res_h", C.c_float), ("vfov_or_size", C.c_float),
-                ("origin", Vec3), ("at", Vec3), ("up", Vec3), ("aperture", C.c_float), ("focus", Vec3)]
+                ("origin", Vec3), ("at", Vec3), ("up", Vec3), ("aperture", C.c_float), ("focus", Vec3),
+                ("animated", C.c_uint32), ("origin_vel", Vec3), ("at_vel", Vec3), ("up_vel", Vec3), ("focus_vel", Vec3)]
 
 
 class WorldDesc(C.Structure):

@@ -391,8 +391,16 @@ RD Scatter bsdf_scatter(const DMaterial& m, f3 wo, f3 normal, const Basis& basis
 }
 
 // ---- cameras (src/camera.rs) ---------------------------------------------------------------------------------
-RD void camera_ray(const DCamera& c, float uvx, float uvy, float lens0, float lens1, f3* out_o, f3* out_d) {
-    f3 o = c.origin, a = c.at, u = c.up;
+// t0 = the ray time of lane 0 of the ray-gen packet: closure-sequenced parameters are evaluated there for all
+// four lanes (WSequenced<Wec3> for F: Fn(f32) -> Vec3, src/animation.rs:62-68)
+RD void camera_ray(const DCamera& c, float uvx, float uvy, float lens0, float lens1, float t0, f3* out_o, f3* out_d) {
+    f3 o = c.origin, a = c.at, u = c.up, fo = c.focus;
+    if (c.animated) {
+        if (c.animated & 1u) o = c.origin + c.origin_vel * t0;
+        if (c.animated & 2u) a = c.at + c.at_vel * t0;
+        if (c.animated & 4u) u = c.up + c.up_vel * t0;
+        if (c.animated & 8u) fo = c.focus + c.focus_vel * t0;
+    }
     if (c.kind == RAYN_CAM_PINHOLE) { // :81-114
         f3 basis_w = normalized(o - a);
         f3 basis_u = normalized(cross(u, basis_w));
@@ -403,7 +411,7 @@ RD void camera_ray(const DCamera& c, float uvx, float uvy, float lens0, float le
         *out_o = o;
         *out_d = normalized(lower_left + horiz + verti - o);
     } else if (c.kind == RAYN_CAM_THIN_LENS) { // :168-208
-        float focus_dist = mag(c.focus - o);
+        float focus_dist = mag(fo - o);
         f3 basis_w = normalized(o - a);
         f3 basis_u = normalized(cross(u, basis_w));
         f3 basis_v = cross(basis_w, basis_u);

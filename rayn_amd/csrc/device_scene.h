@@ -20,6 +20,7 @@ struct DLight { f3 pos; float rad; f3 emission; float _pad; };
 struct DCamera {
     uint32_t kind; float half_w, half_h, full_w, full_h, half_pixel_size, aperture, _pad;
     f3 origin; float _p0; f3 at; float _p1; f3 up; float _p2; f3 focus; float _p3;
+    f3 origin_vel; uint32_t animated; f3 at_vel; float _p4; f3 up_vel; float _p5; f3 focus_vel; float _p6;
 };
 
 struct DScene {

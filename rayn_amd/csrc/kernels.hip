@@ -64,8 +64,9 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
     float uvx = sc.ndc_x * scx, uvy = sc.ndc_y * scy;
     float time = sc.time_start + sc.time_range * sample_1d(tab, spp, s, scr, 0);
     float l0 = sample_2d(tab, spp, 0, s, scr, 1), l1 = sample_2d(tab, spp, 1, s, scr, 1);
+    const float t0 = sc.cam.animated ? sc.time_start + sc.time_range * sample_1d(tab, spp, s & ~3u, scr, 0) : time;
     f3 o, d;
-    camera_ray(sc.cam, uvx, uvy, l0, l1, &o, &d);
+    camera_ray(sc.cam, uvx, uvy, l0, l1, t0, &o, &d);
     pool.geo0[P] = make_float4(o.x, o.y, o.z, d.x);
     pool.geo1[P] = make_float4(d.y, d.z, 0.0f, __uint_as_float(OBJ_NONE | (s << 8)));
     pool.col0[P] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); // WRay::new: radiance 0, throughput 1

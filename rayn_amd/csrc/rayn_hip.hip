@@ -125,6 +125,7 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
     const rayn_camera& c = w.camera;
     DCamera& dc = s.cam;
     dc.kind = c.kind; dc.origin = to3(c.origin); dc.at = to3(c.at); dc.up = to3(c.up); dc.focus = to3(c.focus); dc.aperture = c.aperture;
+    dc.animated = c.animated & 15u; dc.origin_vel = to3(c.origin_vel); dc.at_vel = to3(c.at_vel); dc.up_vel = to3(c.up_vel); dc.focus_vel = to3(c.focus_vel);
     if (c.kind == RAYN_CAM_ORTHOGRAPHIC) { // OrthographicCamera::new, src/camera.rs:228-240
         float aspect = c.res_w / c.res_h;
         float sx = c.vfov_or_size * aspect, sy = c.vfov_or_size;

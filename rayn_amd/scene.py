@@ -145,6 +145,14 @@ class MaterialStore(list):
         return len(self) - 1
 
 
+@dataclass
+class Linear:
+    """The closure `move |t| base + vel * t` (a `Fn(f32) -> Vec3`, src/animation.rs:55-68) as data.  Usable for
+    a camera's origin / at / up / focus; evaluated at lane 0's time of the ray-gen packet like the reference."""
+    base: np.ndarray
+    vel: np.ndarray
+
+
 # ---- Lights / cameras / volume --------------------------------------------------------------
 @dataclass
 class SphereLight:
@@ -265,14 +273,23 @@ class World:
         cam = self.cameras.get(camera)
         c = d.camera
         c.res_w, c.res_h = float(cam.resolution[0]), float(cam.resolution[1])
-        put(c.origin, cam.origin)
-        put(c.at, cam.at)
-        put(c.up, cam.up)
+
+        def put_seq(dst, vel_dst, bit, v):
+            if isinstance(v, Linear):
+                put(dst, v.base)
+                put(vel_dst, v.vel)
+                c.animated |= 1 << bit
+            else:
+                put(dst, v)
+
+        put_seq(c.origin, c.origin_vel, 0, cam.origin)
+        put_seq(c.at, c.at_vel, 1, cam.at)
+        put_seq(c.up, c.up_vel, 2, cam.up)
         if isinstance(cam, PinholeCamera):
             c.kind, c.vfov_or_size = _abi.CAM_PINHOLE, cam.vfov
         elif isinstance(cam, ThinLensCamera):
             c.kind, c.vfov_or_size, c.aperture = _abi.CAM_THIN_LENS, cam.vfov, cam.aperture
-            put(c.focus, cam.focus)
+            put_seq(c.focus, c.focus_vel, 3, cam.focus)
         elif isinstance(cam, OrthographicCamera):
             c.kind, c.vfov_or_size = _abi.CAM_ORTHOGRAPHIC, cam.vertical_size
         else:

@@ -198,6 +198,14 @@ def _custom_world(kind, res):
     elif kind == "ortho":
         world.cameras = R.CameraStore()
         cam_h = world.cameras.add_camera(R.OrthographicCamera(resf, 11.0 / 4.0, R.vec3(9.5, -3.5, 9.5), R.vec3(0.0, 0.8, 0.0), R.vec3(0, 1, 0)))
+    elif kind == "anim_pinhole":  # camera motion blur: origin and up are closures |t| base + vel*t (lane-0 time quirk)
+        world.cameras = R.CameraStore()
+        cam_h = world.cameras.add_camera(R.PinholeCamera(resf, 60.0, R.Linear(origin, R.vec3(6.0, -2.0, 1.0)), R.vec3(0, 0, 0),
+                                                         R.Linear(R.vec3(0, 1, 0), R.vec3(2.0, 0.0, 0.0))))
+    elif kind == "anim_thinlens":
+        world.cameras = R.CameraStore()
+        cam_h = world.cameras.add_camera(R.ThinLensCamera(resf, 50.0, 0.05, origin, R.Linear(R.vec3(0, 0, 0), R.vec3(1.0, 2.0, 0.0)), R.vec3(0, 1, 0),
+                                                          R.Linear(R.vec3(0.2, 0.1, 0.9), R.vec3(0.0, 0.0, -4.0))))
     elif kind == "lambertian":
         world.materials[1] = R.Lambertian(R.Srgb(0.6, 0.3, 0.2))
     elif kind == "no_lights":
@@ -215,7 +223,7 @@ def _custom_world(kind, res):
     return world.to_desc(cam_h)
 
 
-@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere"])
+@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere"])
 def test_closed_set_parity(gpu_ctx, oracle, kind):
     from rayn_amd import params as P
     w, h, samples, bounces = 40, 32, 2, 4
