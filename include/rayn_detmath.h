@@ -123,6 +123,14 @@ RAYN_HD double dm_log_core(double x) {
     return ef * LN2_HI + (ef * LN2_LO + logm);
 }
 
+/* natural log of a float (used by the Mandelbulb distance estimator, an extension outside the reference). */
+RAYN_HD float dm_logf(float xf) {
+    if (dm_isnan(xf) || xf < 0.0f) return dm_nanf();
+    if (xf == 0.0f) return -dm_inff();
+    if (xf == dm_inff()) return xf;
+    return (float)dm_log_core((double)xf);
+}
+
 /* powf for the domain rayn uses (x >= 0 or NaN; src/material.rs:199,236, src/math.rs:108).
  * libm conventions kept: pow(x,0)=1, pow(1,y)=1, pow(0,y>0)=0, negative base -> NaN. */
 RAYN_HD float dm_powf(float xf, float yf) {

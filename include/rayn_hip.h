@@ -51,7 +51,11 @@ typedef enum {
 
 typedef enum {
     RAYN_SDF_SPHERE = 0,   /* sdfu::Sphere: |p| - r (used by BASELINE config 1) */
-    RAYN_SDF_MANDELBOX = 1 /* MandelBox, src/sdf.rs:104-188 */
+    RAYN_SDF_MANDELBOX = 1, /* MandelBox, src/sdf.rs:104-188 */
+    /* EXTENSION, not in the reference (which has no Mandelbulb): power-8 Mandelbulb distance
+     * estimator in the trigonometry-free polynomial form (I. Quilez), 'iterations' orbit steps with bailout
+     * |w|^2 > 256, d = 0.25*ln(m)*sqrt(m)/dz.  Exists because BASELINE.json names the workload "Mandelbulb". */
+    RAYN_SDF_MANDELBULB = 2
 } rayn_sdf_kind;
 
 typedef struct {

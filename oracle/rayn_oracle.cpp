@@ -280,6 +280,39 @@ struct MandelBox : SDF { /* src/sdf.rs:104-188 */
     }
 };
 
+/* EXTENSION, not in the reference: power-8 Mandelbulb DE, polynomial form (I. Quilez, "Mandelbulb"),
+ * bailout |w|^2 > 256 per lane, d = 0.25 ln(m) sqrt(m) / dz.  f32, this exact operation order. */
+struct Mandelbulb : SDF {
+    size_t iterations;
+    F4 dist(W3 pp) const override {
+        tl_dist_evals++;
+        F4 out;
+        for (int l = 0; l < 4; l++) {
+            const float px = pp.x.v[l], py = pp.y.v[l], pz = pp.z.v[l];
+            float wx = px, wy = py, wz = pz;
+            float m = wx * wx + wy * wy + wz * wz, dz = 1.0f;
+            for (size_t i = 0; i < iterations; i++) {
+                float m2 = m * m, m4 = m2 * m2;
+                dz = 8.0f * __builtin_sqrtf(m4 * m2 * m) * dz + 1.0f;
+                float x = wx, x2 = x * x, x4 = x2 * x2;
+                float y = wy, y2 = y * y, y4 = y2 * y2;
+                float z = wz, z2 = z * z, z4 = z2 * z2;
+                float k3 = x2 + z2;
+                float k2 = 1.0f / __builtin_sqrtf(k3 * k3 * k3 * k3 * k3 * k3 * k3);
+                float k1 = x4 + y4 + z4 - 6.0f * y2 * z2 - 6.0f * x2 * y2 + 2.0f * z2 * x2;
+                float k4 = x2 - y2 + z2;
+                wx = px + 64.0f * x * y * z * (x2 - z2) * k4 * (x4 - 6.0f * x2 * z2 + z4) * k1 * k2;
+                wy = py + -16.0f * y2 * k3 * k4 * k4 + k1 * k1;
+                wz = pz + -8.0f * y * k4 * (x4 * x4 - 28.0f * x4 * x2 * z2 + 70.0f * x4 * z4 - 28.0f * x2 * z2 * z4 + z4 * z4) * k1 * k2;
+                m = wx * wx + wy * wy + wz * wz;
+                if (m > 256.0f) break;
+            }
+            out.v[l] = 0.25f * dm_logf(m) * __builtin_sqrtf(m) / dz;
+        }
+        return out;
+    }
+};
+
 /* ------------------------------------------------------------------ Hitable trait --------- */
 struct ShadingInfo { size_t material; WShadingPoint sp; };
 struct Config { uint32_t max_marches, max_vis_marches; float detail_scale; };
@@ -647,6 +680,7 @@ struct World {
             } else {
                 auto t = std::make_unique<TracedSDF>();
                 if (h.sdf_kind == RAYN_SDF_MANDELBOX) t->sdf = std::make_unique<MandelBox>(h.iterations, h.box_side, h.min_radius, h.fixed_radius, h.scale);
+                else if (h.sdf_kind == RAYN_SDF_MANDELBULB) { auto s = std::make_unique<Mandelbulb>(); s->iterations = h.iterations; t->sdf = std::move(s); }
                 else { auto s = std::make_unique<SphereSDF>(); s->radius = F4(h.sdf_radius); t->sdf = std::move(s); }
                 t->material = h.material; t->cfg = cfg;
                 hitables.push_back(std::move(t));

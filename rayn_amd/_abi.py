@@ -8,7 +8,7 @@ MAX_LIGHTS = 16
 FIS_TABLE_SIZE = 512
 
 HITABLE_SPHERE, HITABLE_TRACED_SDF = 0, 1
-SDF_SPHERE, SDF_MANDELBOX = 0, 1
+SDF_SPHERE, SDF_MANDELBOX, SDF_MANDELBULB = 0, 1, 2
 MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_SKY, MAT_EMISSIVE = 0, 1, 2, 3
 CAM_PINHOLE, CAM_THIN_LENS, CAM_ORTHOGRAPHIC = 0, 1, 2
 

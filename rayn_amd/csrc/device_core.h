@@ -126,6 +126,31 @@ RD float fis_sample(const float* __restrict__ inverse_cdf, float u) {
 }
 
 // ---- SDFs (src/sdf.rs:104-188; sdfu::Sphere) ---------------------------------------------------------
+// EXTENSION (not in the reference): power-8 Mandelbulb distance estimator, trigonometry-free polynomial form.
+// Plain IEEE f32 operations in exactly this order (the oracle restates them lane by lane).
+RD float mandelbulb_dist(f3 p, uint32_t iterations) {
+    f3 w = p;
+    float m = w.x * w.x + w.y * w.y + w.z * w.z;
+    float dz = 1.0f;
+    for (uint32_t i = 0; i < iterations; i++) {
+        const float m2 = m * m, m4 = m2 * m2;
+        dz = 8.0f * __builtin_sqrtf(m4 * m2 * m) * dz + 1.0f;
+        const float x = w.x, x2 = x * x, x4 = x2 * x2;
+        const float y = w.y, y2 = y * y, y4 = y2 * y2;
+        const float z = w.z, z2 = z * z, z4 = z2 * z2;
+        const float k3 = x2 + z2;
+        const float k2 = 1.0f / __builtin_sqrtf(k3 * k3 * k3 * k3 * k3 * k3 * k3);
+        const float k1 = x4 + y4 + z4 - 6.0f * y2 * z2 - 6.0f * x2 * y2 + 2.0f * z2 * x2;
+        const float k4 = x2 - y2 + z2;
+        w.x = p.x + 64.0f * x * y * z * (x2 - z2) * k4 * (x4 - 6.0f * x2 * z2 + z4) * k1 * k2;
+        w.y = p.y + -16.0f * y2 * k3 * k4 * k4 + k1 * k1;
+        w.z = p.z + -8.0f * y * k4 * (x4 * x4 - 28.0f * x4 * x2 * z2 + 70.0f * x4 * z4 - 28.0f * x2 * z2 * z4 + z4 * z4) * k1 * k2;
+        m = w.x * w.x + w.y * w.y + w.z * w.z;
+        if (m > 256.0f) break;
+    }
+    return 0.25f * dm_logf(m) * __builtin_sqrtf(m) / dz;
+}
+
 // Correctly rounded n/d for finite normal n, d whose quotient is a normal number: the same Newton-Raphson
 // + residual-correction steps hipcc emits for an IEEE '/', minus v_div_scale / v_div_fixup (which only act
 // on extreme exponents and specials).  22 VALU cycles instead of 36.  The host enables it per object only
@@ -182,6 +207,7 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
 #undef RAYN_DIV_IEEE
         return mag(p) / __builtin_fabsf(dr);
     }
+    if (h.sdf_kind == RAYN_SDF_MANDELBULB) return mandelbulb_dist(p, h.iterations);
     return mag(p) - h.sdf_radius;
 }
 

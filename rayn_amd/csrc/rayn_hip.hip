@@ -109,7 +109,7 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
         }
         if (h.kind == RAYN_HITABLE_TRACED_SDF) {
             s.n_sdf++;
-            if (h.sdf_kind != RAYN_SDF_SPHERE && h.sdf_kind != RAYN_SDF_MANDELBOX) return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown sdf_kind");
+            if (h.sdf_kind != RAYN_SDF_SPHERE && h.sdf_kind != RAYN_SDF_MANDELBOX && h.sdf_kind != RAYN_SDF_MANDELBULB) return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown sdf_kind");
         } else if (h.kind != RAYN_HITABLE_SPHERE) return fail(ctx, RAYN_ERR_INVALID_ARG, "unknown hitable kind");
     }
     for (uint32_t i = 0; i < w.n_materials; i++) {

@@ -82,6 +82,12 @@ class MandelBox:
 
 
 @dataclass
+class Mandelbulb:
+    """EXTENSION (not in the reference): power-8 Mandelbulb DE, polynomial form, bailout 256."""
+    iterations: int = 8
+
+
+@dataclass
 class SphereSDF:
     """sdfu::Sphere::new(radius) — the single-sphere SDF of BASELINE config 1."""
     radius: float
@@ -243,6 +249,9 @@ class World:
                 elif isinstance(s, SphereSDF):
                     o.sdf_kind = _abi.SDF_SPHERE
                     o.sdf_radius = s.radius
+                elif isinstance(s, Mandelbulb):
+                    o.sdf_kind = _abi.SDF_MANDELBULB
+                    o.iterations = s.iterations
                 else:
                     raise TypeError(f"SDF {type(s).__name__} is outside the closed set")
             else:

@@ -3,7 +3,7 @@ config scenes derived from it (S0, S1, S2).  Constants mir
 src/setup.rs:16-44 and src/main.rs:47-56,69."""
 import numpy as np
 
-from .scene import (BoxFold, CameraStore, Dielectric, Emissive, HitableStore, MandelBox, MaterialStore,
+from .scene import (BoxFold, CameraStore, Dielectric, Emissive, HitableStore, MandelBox, Mandelbulb, MaterialStore,
                     PinholeCamera, Sky, Sphere, SphereFold, SphereLight, SphereSDF, Srgb, TracedSDF,
                     VolumeParams, World, vec3, _mul)
 
@@ -36,10 +36,10 @@ def _lights_and_proxies(materials, hitables, lights, with_center_light):
         hitables.push(Sphere(vec3(0.0, 0.0, 0.0), 0.24, green_emissive))
 
 
-def _camera(resolution):
+def _camera(resolution, distance=2.25):
     cameras = CameraStore()
     cam = PinholeCamera((float(resolution[0]), float(resolution[1])), 60.0,
-                        _mul(vec3(-0.45, 0.2, 2.0), 2.25), vec3(0.0, 0.0, 0.0), vec3(0.0, 1.0, 0.0))
+                        _mul(vec3(-0.45, 0.2, 2.0), distance), vec3(0.0, 0.0, 0.0), vec3(0.0, 1.0, 0.0))
     return cameras, cameras.add_camera(cam)
 
 
@@ -56,10 +56,12 @@ def setup(resolution=(1280, 720), volumes=True, sdf="mandelbox"):
         hitables.push(TracedSDF(MandelBox(FRACTAL_ITERATIONS, BoxFold(1.0), SphereFold(0.01, 1.9), -2.1), grey))
     elif sdf == "sphere":
         hitables.push(TracedSDF(SphereSDF(1.0), grey))
+    elif sdf == "mandelbulb":  # extension: the fractal BASELINE.json names; the reference has none
+        hitables.push(TracedSDF(Mandelbulb(8), grey))
     else:
         raise ValueError(sdf)
     _lights_and_proxies(materials, hitables, lights, with_center_light=(sdf == "mandelbox"))
-    cameras, camera = _camera(resolution)
+    cameras, camera = _camera(resolution, 1.35 if sdf == "mandelbulb" else 2.25)  # the bulb is ~1.2 units in radius
     return camera, World(hitables, lights, materials, cameras, volume_params)
 
 
@@ -71,6 +73,12 @@ def setup_s0(resolution=(256, 256)):
 def setup_s1(resolution=(1920, 1080)):
     """BASELINE configs 2/4: shipped MandelBox scene, volumes off."""
     return setup(resolution, volumes=False, sdf="mandelbox")
+
+
+def setup_bulb(resolution=(1920, 1080), volumes=False):
+    """EXTENSION scene: the shipped scene with the MandelBox swapped for a power-8 Mandelbulb (no central light,
+    which would sit inside the bulb)."""
+    return setup(resolution, volumes=volumes, sdf="mandelbulb")
 
 
 def setup_s2(resolution=(1920, 1080)):

@@ -7,7 +7,7 @@ from rayn_amd import setup as S
 
 def case(name, width, height, samples, bounces, **kw):
     """Returns (world_desc, frame_params).  name: s0 (sphere SDF), s1 (MandelBox), s2 (MandelBox + volume)."""
-    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2}[name]((width, height))
+    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "bulb": S.setup_bulb}[name]((width, height))
     return world.to_desc(cam), P.frame_params(width, height, samples, bounces, **kw)
 
 
@@ -19,5 +19,13 @@ def film_l2(a, b):
     return float(np.sqrt(d2).max())
 
 
+def bits_equal(x, y):
+    """Bit equality of float32 arrays; two NaNs compare equal whatever their sign/payload (IEEE 754 leaves the
+    NaN an invalid operation produces unspecified: x86 makes 0xFFC00000, gfx950 0x7FC00000)."""
+    x, y = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32)
+    both_nan = np.isnan(x) & np.isnan(y)
+    return x.shape == y.shape and bool(np.all((x.view(np.uint32) == y.view(np.uint32)) | both_nan))
+
+
 def film_equal_bits(a, b):
-    return all(np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)) for k in ("color", "alpha", "background", "normal"))
+    return all(bits_equal(a[k], b[k]) for k in ("color", "alpha", "background", "normal"))

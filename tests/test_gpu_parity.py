@@ -3,7 +3,7 @@ Bar: per-pixel L2 < 1e-4 (BASELINE.json north_star); the design target is bit-ex
 import numpy as np
 import pytest
 
-from common import case, film_equal_bits, film_l2
+from common import bits_equal, case, film_equal_bits, film_l2
 
 pytestmark = pytest.mark.gpu
 L2_TOL = 1e-4  # north_star: per-pixel L2 < 1e-4 (float)
@@ -52,6 +52,20 @@ def _probe_setup(gpu_ctx, name):
     wd, p = case(name, 64, 64, 1, 3)
     gpu_ctx.upload_world(wd)
     return wd, p
+
+
+def test_mandelbulb_dist_bit_exact(gpu_ctx, oracle):
+    import ctypes as C
+    from rayn_amd._lib import lib
+    wd, p = _probe_setup(gpu_ctx, "bulb")
+    pts = _rand(3 * 200000, -1.6, 1.6, 17).reshape(-1, 3)
+    pts[:100, 0] = 0.0; pts[:100, 2] = 0.0  # the degenerate axis x = z = 0 (k3 = 0 -> inf/NaN), must agree too
+    out = np.zeros(len(pts), np.float32)
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib().rayn_hip_probe_sdf_dist(gpu_ctx.h, C.byref(p), 1, fp(pts), fp(out), len(pts)) == 0
+    ref = oracle.sdf_dist(wd.hitables[1], pts)
+    assert bits_equal(out, ref)
+    assert np.isnan(ref[:100]).all() and np.isfinite(ref[100:]).mean() > 0.99
 
 
 def test_mandelbox_dist_bit_exact(gpu_ctx, oracle):
@@ -111,6 +125,7 @@ FILM_CASES = [
     ("s1", 50, 37, 1, 2, {}),                         # ragged: partial tiles on both axes
     ("s1", 20, 16, 1, 2, {"tile_size": (16, 16)}),    # width 20: reference tile-count quirk (under-coverage)
     ("s2", 32, 32, 1, 2, {"volume_marches": 3}),      # VM = 3: samples_1d[3] doubles as fresnel sample
+    ("bulb", 48, 32, 2, 4, {}),                       # EXTENSION: Mandelbulb DE (not in the reference)
 ]
 
 
