@@ -276,6 +276,7 @@ RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max) {
     float c = mag_sq(oc) - h.radius_sq;
     float descrim = b * b - c;
     bool desc_pos = descrim > 0.0f;
+    if (!desc_pos) return 3.40282347e+38f; // both roots are invalid whatever sqrt returns: skip it (exact)
     float desc_sqrt = __builtin_sqrtf(descrim);
     float t1 = -b - desc_sqrt;
     bool t1_valid = (t1 > 0.0001f) && (t1 <= t_max) && desc_pos;
@@ -294,6 +295,7 @@ RD float sphere_occluded(const DHitable& h, f3 start, f3 end) {
     float c = mag_sq(oc) - h.radius_sq;
     float descrim = b * b - c;
     bool desc_pos = descrim > 0.0f;
+    if (!desc_pos) return 1.0f; // 'valid' needs desc_pos: the segment cannot be occluded by this sphere (exact)
     float desc_sqrt = __builtin_sqrtf(descrim);
     float t1 = -b - desc_sqrt;
     float t2 = -b + desc_sqrt;

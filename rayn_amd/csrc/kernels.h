@@ -53,6 +53,7 @@ struct Tuning {
     uint32_t refill_min_shadow = 8;
     uint32_t prefetch_min_extend = 32;    // fast path: lanes without a spare ray before the bulk queue fetch
     uint32_t prefetch_min_shadow = 32;
+    uint32_t ablate = 0;                  // timing-only debug mask for k_shade_setup (see the kernel)
     bool fast_path = true;                // single-SDF specialisations k_extend1 / k_shadow1
 };
 

@@ -483,8 +483,10 @@ RD bool all_zero(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                       uint32_t depth, const uint32_t* __restrict__ bq, uint32_t n_slots, Pool pool, Nee nee,
-                                                      uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt,
+                                                      uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt, uint32_t ablate,
                                                       unsigned long long* __restrict__ evals_out) {
+    // 'ablate' is a TIMING-ONLY debug mask (RAYN_HIP_ABLATE; results are wrong when non-zero): 1 no normal
+    // estimation, 2 no surface NEE, 4 no BSDF scatter, 8 no sphere occlusion tests, 16 no BSDF::f
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_slots) return; // multiple of 64
     const DScene& sc = *scp;
@@ -559,7 +561,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
         } else { // src/sdf.rs:85-101
             Thr th = make_thr(sc, depth);
             float hps = fmaxs(0.0001f, sc.detail_scale * thr_at(th, t));
-            normal = sdf_normal<COUNT>(h, point, hps, evals);
+            normal = (ablate & 1u) ? f3{0.0f, 1.0f, 0.0f} : sdf_normal<COUNT>(h, point, hps, evals);
             offset_by = hps;
         }
         vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
@@ -571,7 +573,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     const DMaterial& mat = sc.m[sc.h[obj].material];
     const f3 wo = -d;
     // ---- surface NEE, surface_sample_one_light src/integrator.rs:207-240
-    const bool do_surf = valid && receives && nl > 0;
+    const bool do_surf = valid && receives && nl > 0 && !(ablate & 2u);
     {
         if (do_surf) flags |= 2u;
         for (uint32_t i = 0; i < 4; i++) {
@@ -592,7 +594,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
                 // light below the horizon: bsdf.f(..) * 0 is +0 whenever f is finite, which it is for finite
                 // inputs with a non-degenerate half vector -> skip the pow/normalize of BSDF::f (bit-identical)
                 if (cosw == 0.0f && ndw == ndw && mag_sq(wo + wi) > 0.0f) f = f3{0.0f, 0.0f, 0.0f};
-                else f = bsdf_f(mat, wo, wi, normal) * cosw;
+                else f = (ablate & 16u) ? f3{0.1f, 0.1f, 0.1f} * cosw : bsdf_f(mat, wo, wi, normal) * cosw;
                 float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dist) : 1.0f;
                 f3 x = L.emission * f * tr;
                 nee.x[(i * 3 + 0) * cap + j] = x.x; nee.x[(i * 3 + 1) * cap + j] = x.y; nee.x[(i * 3 + 2) * cap + j] = x.z;
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
                 uint8_t vis = 1;
                 // x == 0 (light below the horizon): (x*occluded)/pdf is the same zero for occluded 0 or 1 -> no test needed
                 if (!all_zero(x)) {
-                    if (!spheres_visible(occlude_point, end_point)) vis = 0;
+                    if (!(ablate & 8u) && !spheres_visible(occlude_point, end_point)) vis = 0;
                     else if (scene_has_sdf) { vis = 2; park_job(i, occlude_point, end_point); }
                 }
                 nee.vis[i * cap + j] = vis;
@@ -646,7 +648,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
             const Basis basis = orthonormal_basis(normal);
             const float4 rb = rec[4 + 2 * VM]; // comps 8+8*VM .. +3
             float s3 = s1(3), s4 = s1(4);
-            Scatter se = bsdf_scatter(mat, wo, normal, basis, s3, dm_fractf(rb.x + scr), dm_fractf(rb.y + scr), dm_fractf(rb.z + scr),
+            Scatter se = (ablate & 4u) ? Scatter{normal, f3{0.3f, 0.3f, 0.3f}, 1.0f} : bsdf_scatter(mat, wo, normal, basis, s3, dm_fractf(rb.x + scr), dm_fractf(rb.y + scr), dm_fractf(rb.z + scr),
                                       dm_fractf(rb.w + scr));
             float ndl = __builtin_fabsf(dot(se.wi, normal));
             f3 nthr = thr * vol_T * se.f * ndl / se.pdf;
@@ -1106,8 +1108,8 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
     (void)hipMemsetAsync(counters + 1, 0, 8, s); // [1] shadow job count, [2] shadow queue head
     hooks.before(0);
-    if (count) hipLaunchKernelGGL(k_shade_setup<true>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, evals + 1);
-    else hipLaunchKernelGGL(k_shade_setup<false>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, evals + 1);
+    if (count) hipLaunchKernelGGL(k_shade_setup<true>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+    else hipLaunchKernelGGL(k_shade_setup<false>, grid_for(n_slots, 256), dim3(256), 0, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
     hooks.after(0);
     if (has_sdf) {
         hooks.before(1);
