@@ -126,6 +126,14 @@ FILM_CASES = [
     ("s1", 20, 16, 1, 2, {"tile_size": (16, 16)}),    # width 20: reference tile-count quirk (under-coverage)
     ("s2", 32, 32, 1, 2, {"volume_marches": 3}),      # VM = 3: samples_1d[3] doubles as fresnel sample
     ("bulb", 48, 32, 2, 4, {}),                       # EXTENSION: Mandelbulb DE (not in the reference)
+    ("s1", 16, 16, 1, 0, {}),                         # max_bounces 0: everything terminates at depth 0
+    ("s1", 1, 1, 3, 2, {}),                           # 1x1 film, spp = 12 (not a power of two: resolve sort padding)
+    ("s2", 3, 5, 5, 3, {}),                           # smaller than one tile, spp = 20
+    ("s1", 40, 24, 1, 3, {"tile_size": (8, 4)}),      # small tiles: packet grouping is per tile, so the result differs from 16x16
+    ("s1", 64, 32, 1, 2, {"tile_size": (32, 32)}),    # 1024-pixel tiles (the supported maximum)
+    ("s1", 32, 32, 1, 3, {"frame": 7, "time_range": (0.5, 0.75)}),  # other frame seed + shutter interval
+    ("s1", 32, 16, 1, 2, {"max_marches": 12, "max_vis_marches": 5}),  # march budgets exhausted: 't' is returned as a hit (src/sdf.rs:82)
+    ("s1", 32, 16, 1, 2, {"sdf_detail_scale": 2.0, "world_radius": 20.0}),
 ]
 
 
