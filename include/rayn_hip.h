@@ -225,7 +225,12 @@ uint32_t rayn_tile_count(uint32_t width, uint32_t height, uint32_t tile_w, uint3
 int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals);
 /* out[0] k_extend (closest-hit marches), out[1] k_shade_setup (normal estimation), out[2] k_shadow (NEE visibility) */
 int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
-/* path-pool capacity per batch of tiles (default 2^27 paths: ~40 GB of HBM for a scene without volume). */
+/* A frame's tiles are dealt to up to two workers (host thread + HIP stream + own device memory each) so that one
+ * worker's HBM-bound kernels and readbacks run underneath the other's VALU-bound marches.  n_workers 1|2 (default 2);
+ * frames with fewer than min_paths camera paths use one worker (default 2^22). */
+int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths);
+/* upper limit of the path-pool capacity per worker and batch of tiles (default 2^27 paths, ~45 GB of HBM per worker for a
+ * scene without volume); the effective size is also capped so that all workers together use <= 60 % of the free HBM. */
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
 /* mul_add policy (include/rayn_detmath.h): 0 = unfused a*b+c, what rayn's default x86-64 build does (wide
  * 0.4.6 without +fma) — the DEFAULT; 1 = fused, what rayn built with -C target-feature=+fma does.

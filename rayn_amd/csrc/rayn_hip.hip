@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rayn_detmath.h"
@@ -40,6 +41,26 @@ struct TileRect { uint32_t x0, y0, x1, y1; };
 
 } // namespace
 
+namespace {
+// One worker = one HIP stream + its own slice of device memory, driven by its own host thread.  A frame's
+// tiles are dealt to two workers so that one worker's HBM-bound kernels, queue-size readbacks and kernel
+// tails run underneath the other's VALU-bound march kernels (measured: +6 % on config 2).
+struct Worker {
+    hipStream_t stream = nullptr;
+    Arena arena;
+    uint32_t* h_totals = nullptr;          // pinned
+    unsigned long long* d_evals = nullptr; // [4]
+    hipEvent_t done = nullptr;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+    rayn_stats stats;
+    unsigned long long evals[3] = {0, 0, 0};
+    std::string err;
+    int rc = 0;
+};
+constexpr int MAX_WORKERS = 2;
+} // namespace
+
 struct rayn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -47,27 +68,33 @@ struct rayn_ctx {
     bool have_world = false;
     rayn_world_desc world;
     DScene* d_scene = nullptr;
-    Arena arena;
-    uint32_t* h_totals = nullptr; // pinned
-    unsigned long long* d_evals = nullptr;
+    float4* d_rec = nullptr; size_t rec_cap = 0; // packed sample records (shared by the workers)
+    Worker workers[MAX_WORKERS];
+    hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b = nullptr;
     rayn_stats stats;
     unsigned long long evals[3] = {0, 0, 0}; // extend, shade_setup (normals), shadow
     bool profiling = false, counting = false;
-    size_t batch_paths = (size_t)1 << 27;
+    size_t batch_paths = (size_t)1 << 27;   // per worker; also limited by the HBM budget (render_device)
+    size_t two_worker_min_paths = (size_t)1 << 22;
+    int n_workers = 2;
     Tuning tun;
     int fma_policy = 0; // 0: mul_add unfused (reference default build), 1: fused
-    std::vector<ProfRec> prof;
-    std::vector<hipEvent_t> event_pool;
 };
 
 namespace {
 
 int fail(rayn_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+int wfail(Worker* w, int code, const std::string& msg) { w->err = msg; w->rc = code; return code; }
 
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t e_ = (expr);                                                                               \
         if (e_ != hipSuccess) return fail(ctx, RAYN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define WCHK(expr)                                                                                            \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return wfail(w, RAYN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
 // tile list exactly as render_frame_into builds it, src/film.rs:399-427 (x-major, incl. the
@@ -162,32 +189,34 @@ int validate(rayn_ctx* ctx, const rayn_frame_params* p) {
     return RAYN_OK;
 }
 
-hipEvent_t get_event(rayn_ctx* ctx) {
-    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+hipEvent_t get_event(Worker* w) {
+    if (!w->event_pool.empty()) { hipEvent_t e = w->event_pool.back(); w->event_pool.pop_back(); return e; }
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 
 struct Timed { // brackets one launch with events when profiling is on
-    rayn_ctx* ctx; hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
-    Timed(rayn_ctx* c, hipStream_t st, int cl) : ctx(c), s(st), cls(cl) {
-        if (ctx->profiling) { a = get_event(ctx); b = get_event(ctx); if (a) (void)hipEventRecord(a, s); }
+    Worker* w; bool on; hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Timed(Worker* w_, bool on_, int cl) : w(w_), on(on_), s(w_->stream), cls(cl) {
+        if (on) { a = get_event(w); b = get_event(w); if (a) (void)hipEventRecord(a, s); }
     }
     ~Timed() {
-        if (ctx->profiling && a && b) { (void)hipEventRecord(b, s); ctx->prof.push_back(ProfRec{cls, a, b}); }
+        if (on && a && b) { (void)hipEventRecord(b, s); w->prof.push_back(ProfRec{cls, a, b}); }
     }
 };
 
 void collect_profile(rayn_ctx* ctx) {
     double ms[PC_COUNT] = {0};
-    for (auto& r : ctx->prof) {
-        float t = 0;
-        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
-        ctx->event_pool.push_back(r.a);
-        ctx->event_pool.push_back(r.b);
+    for (Worker& w : ctx->workers) {
+        for (auto& r : w.prof) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
+            w.event_pool.push_back(r.a);
+            w.event_pool.push_back(r.b);
+        }
+        w.prof.clear();
     }
-    ctx->prof.clear();
     ctx->stats.ms_raygen = ms[PC_RAYGEN]; ctx->stats.ms_extend = ms[PC_EXTEND]; ctx->stats.ms_bin = ms[PC_BIN];
     ctx->stats.ms_shade = ms[PC_SHADE]; ctx->stats.ms_compact = ms[PC_COMPACT]; ctx->stats.ms_resolve = ms[PC_RESOLVE];
     ctx->stats.ms_shadow = ms[PC_SHADOW]; ctx->stats.ms_finish = ms[PC_FINISH];
@@ -195,85 +224,76 @@ void collect_profile(rayn_ctx* ctx) {
 
 struct BatchTile { uint32_t tile_index; DTile d; };
 
-int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, const float* d_s2, const float* d_scr, const float* d_fis,
-                  float* d_color, float* d_alpha, float* d_bg, float* d_normal, hipStream_t stream) {
-    int rc = validate(ctx, p);
-    if (rc) return rc;
-    if (!d_s1 || !d_s2 || !d_scr || !d_fis || !d_color || !d_alpha || !d_bg || !d_normal) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
-    HIPCHK(hipSetDevice(ctx->device));
-    DScene hs;
-    rc = build_scene(ctx, ctx->world, *p, &hs);
-    if (rc) return rc;
-    const uint32_t spp = hs.spp;
-    const uint32_t step = p->tile_step ? p->tile_step : 1;
-    if (p->tile_first >= step) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile_first must be < tile_step");
+struct FrameShared { // read-only for the workers
+    const rayn_frame_params* p; DScene hs; Tables tab; const float* d_scr;
+    float *d_color, *d_alpha, *d_bg, *d_normal;
+    KernelSet K; int single_sdf; uint32_t NS; bool count, profiling;
+    size_t batch_paths; // effective per-worker pool capacity of this frame
+};
 
-    // ---- plan: owned tiles -> batches
-    std::vector<TileRect> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
+// everything one worker does for its share of the tiles: batches -> per-depth wavefront -> resolve
+int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector<BatchTile>& mine) {
+    w->rc = 0; w->err.clear();
+    memset(&w->stats, 0, sizeof w->stats);
+    w->evals[0] = w->evals[1] = w->evals[2] = 0;
+    if (mine.empty()) return 0;
+    WCHK(hipSetDevice(ctx->device));
+    const DScene& hs = F.hs;
+    const uint32_t spp = hs.spp, NS = F.NS;
+    const KernelSet& K = F.K;
+    hipStream_t stream = w->stream;
+    // ---- batches of whole tiles that fit the path pool
     std::vector<std::vector<BatchTile>> batches;
     size_t max_pool = 0, max_tiles = 0;
     uint32_t max_tile_pixels = 0;
     {
         std::vector<BatchTile> cur;
         size_t pool = 0;
-        for (uint32_t k = p->tile_first; k < tiles.size(); k += step) {
-            const TileRect& t = tiles[k];
-            uint32_t ew = t.x1 - t.x0, eh = t.y1 - t.y0;
-            if (!ew || !eh) continue;
-            size_t n = (size_t)ew * eh * spp, na = (n + 63) & ~(size_t)63;
-            if (!cur.empty() && pool + na > ctx->batch_paths) {
+        for (const BatchTile& t : mine) {
+            size_t n = t.d.n_paths, na = (n + 63) & ~(size_t)63;
+            if (!cur.empty() && pool + na > F.batch_paths) {
                 max_pool = std::max(max_pool, pool); max_tiles = std::max(max_tiles, cur.size());
                 batches.push_back(std::move(cur)); cur.clear(); pool = 0;
             }
-            BatchTile bt; bt.tile_index = k;
-            bt.d = DTile{t.x0, t.y0, ew, eh, (uint32_t)pool, (uint32_t)n, {0, 0}};
+            BatchTile bt = t;
+            bt.d.pool_base = (uint32_t)pool;
             cur.push_back(bt);
             pool += na;
-            max_tile_pixels = std::max(max_tile_pixels, ew * eh);
+            max_tile_pixels = std::max(max_tile_pixels, t.d.ew * t.d.eh);
         }
         if (!cur.empty()) { max_pool = std::max(max_pool, pool); max_tiles = std::max(max_tiles, cur.size()); batches.push_back(std::move(cur)); }
     }
-    memset(&ctx->stats, 0, sizeof ctx->stats);
-    ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
-    if (batches.empty()) return RAYN_OK;
-
     // ---- device memory: one arena sized for the largest batch
     const size_t CAP = max_pool;                                   // pool slots
     const size_t QCAP = CAP + max_tiles * 64;                      // ray queue slots (tile tails)
     const size_t BCAP = CAP + max_tiles * (SCAN_NC_BIN * 3 + 64);  // binned slots (x4 bin padding + tails)
-
     const size_t QG = QCAP / 64 + 1, BG = BCAP / 64 + 1;
+    const size_t JOBCAP = (size_t)NS * BCAP;
+    if (JOBCAP >= ((size_t)1 << 32) || BCAP >= ((size_t)1 << 31)) return wfail(w, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
     size_t need = 0;
     auto acc = [&](size_t n, size_t sz) { need += (n * sz + 255) & ~(size_t)255; };
     for (int i = 0; i < 5; i++) acc(CAP, 16);
     acc(CAP, 4); acc(CAP, 1);                                                                      // pool records + termination
-    need += 256 * 32;                                                                              // alignment slack for the separate pool arrays
     acc(QCAP, 4); acc(QCAP, 4); acc(BCAP, 4); acc(QCAP, 1); acc(BCAP, 1);                          // q, qn, bq, ent_obj, alive
     acc(QG * SCAN_NC_BIN, 1); acc(QG * SCAN_NC_BIN, 4); acc(QG, 4);                                // grp_cnt, grp_base, grp_tile
     acc(BG, 1); acc(BG, 4); acc(BG, 4);                                                            // bgrp_*
     acc(max_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                           // tiles, pgrp_tile
     for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
     acc(2, 4); acc(8, 4);
-    acc((size_t)(p->max_bounces + 1) * spp * ((8 + 12 + 8 * p->volume_marches) / 4), 16); // packed sample records
-    const uint32_t NS = 4 + (ctx->world.has_scattering ? 4 * p->volume_marches : 0); // NEE samples per shading point
-    const size_t JOBCAP = (size_t)NS * BCAP;
-    if (JOBCAP >= ((size_t)1 << 32) || BCAP >= ((size_t)1 << 31)) return fail(ctx, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
     acc(NS * 3 * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);
     acc(JOBCAP, 4); acc(2 * JOBCAP, 16);
-    if (need > ctx->arena.cap) {
-        if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
-        ctx->arena.base = nullptr; ctx->arena.cap = 0;
+    if (need > w->arena.cap) {
+        if (w->arena.base) WCHK(hipFree(w->arena.base));
+        w->arena.base = nullptr; w->arena.cap = 0;
         void* ptr = nullptr;
-        if (hipMalloc(&ptr, need) != hipSuccess) return fail(ctx, RAYN_ERR_OOM, "hipMalloc of the path pool failed (" + std::to_string(need >> 20) + " MiB)");
-        ctx->arena.base = (char*)ptr; ctx->arena.cap = need;
+        if (hipMalloc(&ptr, need) != hipSuccess) return wfail(w, RAYN_ERR_OOM, "hipMalloc of the path pool failed (" + std::to_string(need >> 20) + " MiB)");
+        w->arena.base = (char*)ptr; w->arena.cap = need;
     }
-    Arena& A = ctx->arena;
+    Arena& A = w->arena;
     A.off = 0;
     Pool pool;
     pool.geo0 = A.take<float4>(CAP); pool.geo1 = A.take<float4>(CAP); pool.col0 = A.take<float4>(CAP); pool.col1 = A.take<float4>(CAP);
     pool.aov = A.take<float4>(CAP); pool.term_key = A.take<uint32_t>(CAP); pool.term_info = A.take<uint8_t>(CAP);
-    const uint32_t rec_stride = (8 + hs.n2) / 4, rec_depths = p->max_bounces + 1;
-    float4* d_rec = A.take<float4>((size_t)rec_depths * spp * rec_stride);
     uint32_t* q = A.take<uint32_t>(QCAP); uint32_t* qn = A.take<uint32_t>(QCAP); uint32_t* bq = A.take<uint32_t>(BCAP);
     uint8_t* ent_obj = A.take<uint8_t>(QCAP); uint8_t* alive = A.take<uint8_t>(BCAP);
     uint8_t* grp_cnt = A.take<uint8_t>(QG * SCAN_NC_BIN); uint32_t* grp_base = A.take<uint32_t>(QG * SCAN_NC_BIN); uint32_t* grp_tile = A.take<uint32_t>(QG);
@@ -289,19 +309,11 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     nee.x = A.take<float>(NS * 3 * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
     nee.vis = A.take<uint8_t>(NS * BCAP); nee.T = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
     nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float4>(2 * JOBCAP);
-    if (A.off > A.cap) return fail(ctx, RAYN_ERR_OOM, "internal: arena under-sized");
+    if (A.off > A.cap) return wfail(w, RAYN_ERR_OOM, "internal: arena under-sized");
 
-    hipEvent_t ev_a = get_event(ctx), ev_b = get_event(ctx);
-    HIPCHK(hipEventRecord(ev_a, stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_scene, &hs, sizeof hs, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(ctx->d_evals, 0, 32, stream));
-    const KernelSet K = kernel_set(ctx->fma_policy);
-    int single_sdf = -1; // index of the TracedSDF when the scene holds exactly one (fast-path kernels)
-    if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) single_sdf = (int)i;
-    const Tables tab{d_s1, d_s2, d_fis, d_rec, rec_stride};
-    K.pack_tables(stream, tab, d_rec, spp, rec_depths, hs.n1, hs.n2);
-    const bool count = ctx->counting;
-
+    WCHK(hipMemsetAsync(w->d_evals, 0, 32, stream));
+    const bool count = F.count, prof = F.profiling;
+    const Tables& tab = F.tab;
     std::vector<DTile> h_tiles; std::vector<uint32_t> h_pgrp, h_tgb, h_tgc;
     for (auto& batch : batches) {
         const uint32_t nt = (uint32_t)batch.size();
@@ -314,84 +326,170 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
             h_tgb[i] = batch[i].d.pool_base / 64; h_tgc[i] = groups;
             h_pgrp.insert(h_pgrp.end(), groups, i);
             n_pool += (size_t)groups * 64;
-            ctx->stats.paths += batch[i].d.n_paths;
+            w->stats.paths += batch[i].d.n_paths;
         }
-        ctx->stats.tiles += nt; ctx->stats.batches++;
+        w->stats.tiles += nt; w->stats.batches++;
         // the staging vectors are reused by the next batch: finish these copies before going on
-        HIPCHK(hipMemcpyAsync(d_tiles, h_tiles.data(), nt * sizeof(DTile), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(pgrp_tile, h_pgrp.data(), h_pgrp.size() * 4, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(tgbA, h_tgb.data(), nt * 4, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(tgcA, h_tgc.data(), nt * 4, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        WCHK(hipMemcpyAsync(d_tiles, h_tiles.data(), nt * sizeof(DTile), hipMemcpyHostToDevice, stream));
+        WCHK(hipMemcpyAsync(pgrp_tile, h_pgrp.data(), h_pgrp.size() * 4, hipMemcpyHostToDevice, stream));
+        WCHK(hipMemcpyAsync(tgbA, h_tgb.data(), nt * 4, hipMemcpyHostToDevice, stream));
+        WCHK(hipMemcpyAsync(tgcA, h_tgc.data(), nt * 4, hipMemcpyHostToDevice, stream));
+        WCHK(hipStreamSynchronize(stream));
 
-        { Timed t(ctx, stream, PC_RAYGEN); K.raygen(stream, ctx->d_scene, tab, d_scr, d_tiles, pgrp_tile, pool, q, (uint32_t)n_pool); }
+        { Timed t(w, prof, PC_RAYGEN); K.raygen(stream, ctx->d_scene, tab, F.d_scr, d_tiles, pgrp_tile, pool, q, (uint32_t)n_pool); }
         uint32_t n_entries = (uint32_t)n_pool;
         uint32_t* qcur = q; uint32_t* qnext = qn;
         for (uint32_t depth = 0; n_entries > 0; depth++) {
-            { Timed t(ctx, stream, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, single_sdf, d_counters, ctx->d_evals, ctx->tun); }
-            ctx->stats.launches_extend++;
+            { Timed t(w, prof, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, F.single_sdf, d_counters, w->d_evals, ctx->tun); }
+            w->stats.launches_extend++;
             {
-                Timed t(ctx, stream, PC_BIN);
+                Timed t(w, prof, PC_BIN);
                 K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid);
                 K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_totals);
             }
-            HIPCHK(hipMemcpyAsync(ctx->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            const uint32_t n_slots = ctx->h_totals[0] * 64, n_hits = ctx->h_totals[1];
-            ctx->stats.segments += n_hits;
+            WCHK(hipMemcpyAsync(w->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
+            WCHK(hipStreamSynchronize(stream));
+            const uint32_t n_slots = w->h_totals[0] * 64, n_hits = w->h_totals[1];
+            w->stats.segments += n_hits;
             if (n_hits == 0) break;
-            if (n_slots > BCAP) return fail(ctx, RAYN_ERR_OOM, "internal: binned queue overflow");
+            if (n_slots > BCAP) return wfail(w, RAYN_ERR_OOM, "internal: binned queue overflow");
             {
-                Timed t(ctx, stream, PC_BIN);
-                HIPCHK(hipMemsetAsync(bq, 0xFF, (size_t)n_slots * 4, stream));
+                Timed t(w, prof, PC_BIN);
+                WCHK(hipMemsetAsync(bq, 0xFF, (size_t)n_slots * 4, stream));
                 K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
             }
             // group_hist reads 1 B/entry; scatter reads q (4) + ent_obj (1), writes bq (4); memset writes bq (4); scans ~17 B/group
-            ctx->stats.queue_bytes_bin += (uint64_t)n_entries * (1 + 4 + 1) + (uint64_t)n_slots * (4 + 4) + (uint64_t)(n_entries / 64) * 85;
+            w->stats.queue_bytes_bin += (uint64_t)n_entries * (1 + 4 + 1) + (uint64_t)n_slots * (4 + 4) + (uint64_t)(n_entries / 64) * 85;
             {
                 static const int cls[3] = {PC_SHADE, PC_SHADOW, PC_FINISH};
-                struct HookState { rayn_ctx* ctx; hipStream_t s; Timed* cur; } hst{ctx, stream, nullptr};
+                struct HookState { Worker* w; bool on; Timed* cur; } hst{w, prof, nullptr};
                 ShadeHooks hooks;
                 hooks.user = &hst;
-                hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->ctx, h->s, cls[i]); };
+                hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->w, h->on, cls[i]); };
                 hooks.after_fn = [](void* u, int) { HookState* h = (HookState*)u; delete h->cur; h->cur = nullptr; };
-                K.shade(stream, count, ctx->d_scene, tab, d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, single_sdf, alive, bgrp_cnt, d_counters, ctx->d_evals, hooks, ctx->tun);
+                K.shade(stream, count, ctx->d_scene, tab, F.d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, F.single_sdf, alive, bgrp_cnt, d_counters, w->d_evals, hooks, ctx->tun);
             }
-            ctx->stats.launches_shade++;
-            ctx->stats.shaded_slots += n_slots;
+            w->stats.launches_shade++;
+            w->stats.shaded_slots += n_slots;
             {
-                Timed t(ctx, stream, PC_COMPACT);
+                Timed t(w, prof, PC_COMPACT);
                 K.scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid);
                 K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_totals);
             }
-            HIPCHK(hipMemcpyAsync(ctx->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            const uint32_t n_next = ctx->h_totals[0] * 64, n_alive = ctx->h_totals[1];
+            WCHK(hipMemcpyAsync(w->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
+            WCHK(hipStreamSynchronize(stream));
+            const uint32_t n_next = w->h_totals[0] * 64, n_alive = w->h_totals[1];
             if (n_alive == 0) break;
-            if (n_next > QCAP) return fail(ctx, RAYN_ERR_OOM, "internal: ray queue overflow");
+            if (n_next > QCAP) return wfail(w, RAYN_ERR_OOM, "internal: ray queue overflow");
             {
-                Timed t(ctx, stream, PC_COMPACT);
-                HIPCHK(hipMemsetAsync(qnext, 0xFF, (size_t)n_next * 4, stream));
+                Timed t(w, prof, PC_COMPACT);
+                WCHK(hipMemsetAsync(qnext, 0xFF, (size_t)n_next * 4, stream));
                 K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, n_slots, qnext);
             }
             // compact_scatter reads bq (4) + alive (1), writes q' (4); memset writes q' (4); scans ~9 B/group
-            ctx->stats.queue_bytes_compact += (uint64_t)n_slots * (4 + 1) + (uint64_t)n_next * (4 + 4) + (uint64_t)(n_slots / 64) * 9;
+            w->stats.queue_bytes_compact += (uint64_t)n_slots * (4 + 1) + (uint64_t)n_next * (4 + 4) + (uint64_t)(n_slots / 64) * 9;
             std::swap(qcur, qnext);
             n_entries = n_next;
         }
-        { Timed t(ctx, stream, PC_RESOLVE); K.resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, d_color, d_alpha, d_bg, d_normal); }
+        { Timed t(w, prof, PC_RESOLVE); K.resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, F.d_color, F.d_alpha, F.d_bg, F.d_normal); }
     }
-    HIPCHK(hipEventRecord(ev_b, stream));
+    WCHK(hipEventRecord(w->done, stream));
+    WCHK(hipStreamSynchronize(stream));
+    WCHK(hipGetLastError());
+    if (count) WCHK(hipMemcpy(w->evals, w->d_evals, 24, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, const float* d_s2, const float* d_scr, const float* d_fis,
+                  float* d_color, float* d_alpha, float* d_bg, float* d_normal, hipStream_t stream) {
+    int rc = validate(ctx, p);
+    if (rc) return rc;
+    if (!d_s1 || !d_s2 || !d_scr || !d_fis || !d_color || !d_alpha || !d_bg || !d_normal) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
+    HIPCHK(hipSetDevice(ctx->device));
+    FrameShared F;
+    F.p = p;
+    rc = build_scene(ctx, ctx->world, *p, &F.hs);
+    if (rc) return rc;
+    const DScene& hs = F.hs;
+    const uint32_t spp = hs.spp;
+    const uint32_t step = p->tile_step ? p->tile_step : 1;
+    if (p->tile_first >= step) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile_first must be < tile_step");
+
+    // ---- plan: owned tiles, dealt alternately to the workers
+    std::vector<TileRect> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
+    std::vector<BatchTile> owned;
+    size_t owned_paths = 0;
+    for (uint32_t k = p->tile_first; k < tiles.size(); k += step) {
+        const TileRect& t = tiles[k];
+        uint32_t ew = t.x1 - t.x0, eh = t.y1 - t.y0;
+        if (!ew || !eh) continue;
+        BatchTile bt; bt.tile_index = k;
+        bt.d = DTile{t.x0, t.y0, ew, eh, 0u, (uint32_t)((size_t)ew * eh * spp), {0, 0}};
+        owned.push_back(bt);
+        owned_paths += bt.d.n_paths;
+    }
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
+    if (owned.empty()) return RAYN_OK;
+    const int nw = (ctx->n_workers >= 2 && owned_paths >= ctx->two_worker_min_paths && owned.size() >= 2) ? 2 : 1;
+    std::vector<BatchTile> share[MAX_WORKERS];
+    for (size_t i = 0; i < owned.size(); i++) share[i % nw].push_back(owned[i]);
+
+    // ---- shared, read-only state: scene, tables, packed sample records
+    const uint32_t rec_stride = (8 + hs.n2) / 4, rec_depths = p->max_bounces + 1;
+    const size_t rec_n = (size_t)rec_depths * spp * rec_stride;
+    if (rec_n > ctx->rec_cap) {
+        if (ctx->d_rec) HIPCHK(hipFree(ctx->d_rec));
+        ctx->d_rec = nullptr; ctx->rec_cap = 0;
+        if (hipMalloc((void**)&ctx->d_rec, rec_n * 16) != hipSuccess) return fail(ctx, RAYN_ERR_OOM, "hipMalloc of the packed sample records failed");
+        ctx->rec_cap = rec_n;
+    }
+    HIPCHK(hipEventRecord(ctx->ev_a, stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_scene, &F.hs, sizeof F.hs, hipMemcpyHostToDevice, stream));
+    F.K = kernel_set(ctx->fma_policy);
+    F.single_sdf = -1; // index of the TracedSDF when the scene holds exactly one (fast-path kernels)
+    if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) F.single_sdf = (int)i;
+    F.tab = Tables{d_s1, d_s2, d_fis, ctx->d_rec, rec_stride};
+    F.K.pack_tables(stream, F.tab, ctx->d_rec, spp, rec_depths, hs.n1, hs.n2);
+    F.d_scr = d_scr; F.d_color = d_color; F.d_alpha = d_alpha; F.d_bg = d_bg; F.d_normal = d_normal;
+    F.NS = 4 + (ctx->world.has_scattering ? 4 * p->volume_marches : 0); // NEE samples per shading point
+    F.count = ctx->counting; F.profiling = ctx->profiling;
+    {   // bigger batches = fewer launches and tails (measured 2^25 -> 2^27 paths: -9 % frame time): size them for the HBM
+        // that is actually free, at most 60 % of it across the workers (the rest stays for the caller: film, tables, torch)
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        for (const Worker& w : ctx->workers) free_b += w.arena.cap;
+        const size_t per_path = 101 + 53 * (size_t)F.NS + 4 * ((size_t)F.NS - 3) + 17; // pool + queues + NEE records + shadow segments
+        const size_t fit = (size_t)(0.6 * (double)free_b) / (size_t)nw / per_path;
+        F.batch_paths = std::max<size_t>(4096, std::min(ctx->batch_paths, fit));
+    }
+    // fork: the worker streams start after everything already queued on the caller's stream
+    HIPCHK(hipEventRecord(ctx->ev_fork, stream));
+    HIPCHK(hipStreamSynchronize(stream)); // F.hs is on this stack frame: make sure the scene copy has been consumed
+    for (int i = 0; i < nw; i++) HIPCHK(hipStreamWaitEvent(ctx->workers[i].stream, ctx->ev_fork, 0));
+    if (nw == 1) run_worker(ctx, &ctx->workers[0], F, share[0]);
+    else {
+        std::thread t1([&]() { run_worker(ctx, &ctx->workers[1], F, share[1]); });
+        run_worker(ctx, &ctx->workers[0], F, share[0]);
+        t1.join();
+    }
+    // join: the caller's stream continues after both workers
+    for (int i = 0; i < nw; i++) {
+        Worker& w = ctx->workers[i];
+        if (w.rc) return fail(ctx, w.rc, w.err);
+        if (!share[i].empty()) HIPCHK(hipStreamWaitEvent(stream, w.done, 0));
+        ctx->stats.paths += w.stats.paths; ctx->stats.segments += w.stats.segments; ctx->stats.shaded_slots += w.stats.shaded_slots;
+        ctx->stats.tiles += w.stats.tiles; ctx->stats.batches += w.stats.batches;
+        ctx->stats.launches_extend += w.stats.launches_extend; ctx->stats.launches_shade += w.stats.launches_shade;
+        ctx->stats.queue_bytes_bin += w.stats.queue_bytes_bin; ctx->stats.queue_bytes_compact += w.stats.queue_bytes_compact;
+        for (int k = 0; k < 3; k++) ctx->evals[k] += w.evals[k];
+    }
+    HIPCHK(hipEventRecord(ctx->ev_b, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    HIPCHK(hipGetLastError());
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev_a, ev_b);
+    (void)hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
     ctx->stats.ms_total = ms;
-    ctx->event_pool.push_back(ev_a); ctx->event_pool.push_back(ev_b);
     if (ctx->profiling) collect_profile(ctx);
-    if (count) {
-        HIPCHK(hipMemcpy(ctx->evals, ctx->d_evals, 24, hipMemcpyDeviceToHost));
-    }
     return RAYN_OK;
 }
 
@@ -408,12 +506,14 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     rayn_ctx* ctx = new rayn_ctx();
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof ctx->stats);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_scene, sizeof(DScene)) != hipSuccess || hipMalloc((void**)&ctx->d_evals, 32) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->h_totals, 16) != hipSuccess) {
-        delete ctx;
-        return RAYN_ERR_HIP;
-    }
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&ctx->stream) == hipSuccess &&
+              hipMalloc((void**)&ctx->d_scene, sizeof(DScene)) == hipSuccess && hipEventCreate(&ctx->ev_a) == hipSuccess &&
+              hipEventCreate(&ctx->ev_b) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (Worker& w : ctx->workers)
+        ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess && hipMalloc((void**)&w.d_evals, 32) == hipSuccess &&
+             hipHostMalloc((void**)&w.h_totals, 16) == hipSuccess && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { rayn_hip_destroy(ctx); return RAYN_ERR_HIP; }
+    if (const char* e = getenv("RAYN_HIP_WORKERS")) ctx->n_workers = atoi(e);
     if (const char* e = getenv("RAYN_HIP_BATCH_PATHS")) { long long v = atoll(e); if (v >= 4096) ctx->batch_paths = (size_t)v; }
     if (const char* e = getenv("RAYN_HIP_PROFILE")) ctx->profiling = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_REFILL_EXTEND")) ctx->tun.refill_min_extend = (uint32_t)std::max(1, atoi(e));
@@ -431,11 +531,20 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    for (Worker& w : ctx->workers) {
+        if (w.stream) (void)hipStreamSynchronize(w.stream);
+        for (auto e : w.event_pool) (void)hipEventDestroy(e);
+        if (w.arena.base) (void)hipFree(w.arena.base);
+        if (w.d_evals) (void)hipFree(w.d_evals);
+        if (w.h_totals) (void)hipHostFree(w.h_totals);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
+    if (ctx->d_rec) (void)hipFree(ctx->d_rec);
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
-    if (ctx->d_evals) (void)hipFree(ctx->d_evals);
-    if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
+    if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -577,6 +686,12 @@ int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const flo
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
     hipFree(d_a); hipFree(d_b); hipFree(d_out);
+    return RAYN_OK;
+}
+int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths) {
+    if (!ctx || n_workers < 1 || n_workers > MAX_WORKERS) return RAYN_ERR_INVALID_ARG;
+    ctx->n_workers = n_workers;
+    ctx->two_worker_min_paths = (size_t)min_paths;
     return RAYN_OK;
 }
 int rayn_hip_fma_policy(void) { return 0; }

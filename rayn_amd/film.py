@@ -70,6 +70,9 @@ class Context:
         """0 = unfused mul_add (reference default build, the default), 1 = fused (rayn built with +fma)."""
         self._chk(self._L.rayn_hip_set_fma_policy(self.h, int(policy)))
 
+    def set_workers(self, n_workers, min_paths=1 << 22):
+        self._chk(self._L.rayn_hip_set_workers(self.h, int(n_workers), int(min_paths)))
+
     def set_batch_paths(self, n):
         self._chk(self._L.rayn_hip_set_batch_paths(self.h, int(n)))
 

@@ -166,6 +166,30 @@ def test_batching_is_invisible(gpu_ctx, oracle):
     assert film_equal_bits(a, b)
 
 
+def test_two_workers_are_invisible(gpu_ctx, oracle):
+    """The two-worker pipeline (two host threads / streams) on a small frame, with several batches per worker."""
+    wd, p = case("s2", 64, 48, 2, 3)
+    tabs = _tables(oracle, p)
+    ref, ctr = oracle.render(wd, p, tabs)
+    gpu_ctx.upload_world(wd)
+    gpu_ctx.set_workers(2, 0)
+    gpu_ctx.set_batch_paths(8192)
+    try:
+        out = gpu_ctx.render_host(p, tabs)
+        st = gpu_ctx.stats()
+    finally:
+        gpu_ctx.set_workers(2)
+        gpu_ctx.set_batch_paths(1 << 27)
+    assert st["batches"] >= 4 and st["paths"] == ctr.paths and st["segments"] == ctr.segments
+    assert film_equal_bits(out, ref)
+    gpu_ctx.set_workers(1)
+    try:
+        one = gpu_ctx.render_host(p, tabs)
+    finally:
+        gpu_ctx.set_workers(2)
+    assert film_equal_bits(one, ref)
+
+
 def test_tile_partition_union(gpu_ctx, oracle):
     """tile_first/tile_step (the multi-GPU film partition): the union of the strided renders == the full frame."""
     wd, p = case("s1", 64, 48, 1, 2)
