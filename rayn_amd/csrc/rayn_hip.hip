@@ -58,7 +58,7 @@ struct Worker {
     std::string err;
     int rc = 0;
 };
-constexpr int MAX_WORKERS = 2;
+constexpr int MAX_WORKERS = 4;
 } // namespace
 
 struct rayn_ctx {
@@ -431,7 +431,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
     if (owned.empty()) return RAYN_OK;
-    const int nw = (ctx->n_workers >= 2 && owned_paths >= ctx->two_worker_min_paths && owned.size() >= 2) ? 2 : 1;
+    int nw = 1;
+    if (ctx->n_workers >= 2 && owned_paths >= ctx->two_worker_min_paths) nw = (int)std::min<size_t>((size_t)std::min(ctx->n_workers, MAX_WORKERS), owned.size());
     std::vector<BatchTile> share[MAX_WORKERS];
     for (size_t i = 0; i < owned.size(); i++) share[i % nw].push_back(owned[i]);
 
@@ -467,11 +468,11 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     HIPCHK(hipEventRecord(ctx->ev_fork, stream));
     HIPCHK(hipStreamSynchronize(stream)); // F.hs is on this stack frame: make sure the scene copy has been consumed
     for (int i = 0; i < nw; i++) HIPCHK(hipStreamWaitEvent(ctx->workers[i].stream, ctx->ev_fork, 0));
-    if (nw == 1) run_worker(ctx, &ctx->workers[0], F, share[0]);
-    else {
-        std::thread t1([&]() { run_worker(ctx, &ctx->workers[1], F, share[1]); });
+    {
+        std::vector<std::thread> threads;
+        for (int i = 1; i < nw; i++) threads.emplace_back([&, i]() { run_worker(ctx, &ctx->workers[i], F, share[i]); });
         run_worker(ctx, &ctx->workers[0], F, share[0]);
-        t1.join();
+        for (auto& t : threads) t.join();
     }
     // join: the caller's stream continues after both workers
     for (int i = 0; i < nw; i++) {
