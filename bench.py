@@ -118,6 +118,8 @@ def main():
     if not args.no_roofline:
         # (1) per-kernel-class HIP-event timing with the production kernels, (2) SDF-evaluation counts with
         # the instrumented variants.  Both outside the timed region.
+        # per-kernel event times are only meaningful without the two-worker overlap: profile with ONE worker
+        ctx.set_workers(1)
         ctx.set_profiling(True, False)
         ctx.render_device(p, d_tabs, film)
         torch.cuda.synchronize()
@@ -127,6 +129,7 @@ def main():
         torch.cuda.synchronize()
         ev = ctx.eval_counts()
         ctx.set_profiling(False, False)
+        ctx.set_workers(2)
         classes = {"extend": (st["ms_extend"], ev["extend"], st["launches_extend"]), "shadow": (st["ms_shadow"], ev["shadow"], st["launches_shade"]),
                    "shade_setup": (st["ms_shade"], ev["shade_setup"], st["launches_shade"])}
         dom = max(classes, key=lambda k: classes[k][0])
