@@ -241,6 +241,13 @@ int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy);
  * 4 material, 5 light, 6 camera — lets a binding verify its layout. */
 size_t rayn_hip_sizeof(int which);
 
+/* Packet-order dump of ONE tile of the next renders (diagnostics; tile_index in the reference's tile order, -1 = off):
+ * after every depth's bin stage the tile's binned queue is read back as records of 6 u32 {depth, object, tile x,
+ * tile y, sample, valid} in HitStore::process_hits order (src/hitable.rs:94-134: object-major, insertion order, bins
+ * padded to x4 with invalid lanes).  rayn_hip_get_trace returns the record count and copies up to cap_records. */
+int rayn_hip_set_trace_tile(rayn_ctx* ctx, int tile_index);
+int64_t rayn_hip_get_trace(const rayn_ctx* ctx, uint32_t* out, uint64_t cap_records);
+
 /* ---- test probes: device per-lane primitives on caller data (HOST pointers).  They exist so the
  * parity tests can compare single functions with the CPU oracle lane for lane:
  *   SDF::dist (src/sdf.rs:125-140), HitableStore::add_hits' closest hit (src/hitable.rs:177-198;

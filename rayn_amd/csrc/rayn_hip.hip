@@ -78,6 +78,8 @@ struct rayn_ctx {
     size_t two_worker_min_paths = (size_t)1 << 22;
     int n_workers = 2;
     Tuning tun;
+    int trace_tile = -1;             // diagnostics: dump the packet order of this tile (rayn_hip_set_trace_tile)
+    std::vector<uint32_t> trace;     // records of 6 u32: depth, object, tile x, tile y, sample, valid
     int fma_policy = 0; // 0: mul_add unfused (reference default build), 1: fused
 };
 
@@ -358,6 +360,33 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
                 WCHK(hipMemsetAsync(bq, 0xFF, (size_t)n_slots * 4, stream));
                 K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
             }
+            if (ctx->trace_tile >= 0) { // diagnostics only: packet order of one tile, in HitStore::process_hits order
+                for (uint32_t i = 0; i < nt; i++) {
+                    if ((int)batch[i].tile_index != ctx->trace_tile) continue;
+                    const DTile& td = batch[i].d;
+                    uint32_t base = 0, total = 0;
+                    WCHK(hipMemcpy(&base, tile_out_base + i, 4, hipMemcpyDeviceToHost));
+                    WCHK(hipMemcpy(&total, tile_total + i, 4, hipMemcpyDeviceToHost));
+                    std::vector<uint32_t> hq(total);
+                    std::vector<float4> g1(td.n_paths), c1(td.n_paths);
+                    WCHK(hipMemcpy(hq.data(), bq + base, (size_t)total * 4, hipMemcpyDeviceToHost));
+                    WCHK(hipMemcpy(g1.data(), pool.geo1 + td.pool_base, (size_t)td.n_paths * 16, hipMemcpyDeviceToHost));
+                    WCHK(hipMemcpy(c1.data(), pool.col1 + td.pool_base, (size_t)td.n_paths * 16, hipMemcpyDeviceToHost));
+                    uint32_t packet_obj = 0;
+                    for (uint32_t s = 0; s < total; s++) {
+                        const uint32_t P = hq[s];
+                        uint32_t rec[6] = {depth, packet_obj, 0, 0, 0, 0};
+                        if (P != INVALID) {
+                            uint32_t bits, pix;
+                            memcpy(&bits, &g1[P - td.pool_base].w, 4);
+                            memcpy(&pix, &c1[P - td.pool_base].z, 4);
+                            rec[1] = bits & 0xFFu; rec[2] = pix % hs.width - td.x0; rec[3] = pix / hs.width - td.y0; rec[4] = bits >> 8; rec[5] = 1;
+                            if ((s & 3u) == 0) packet_obj = rec[1]; // a packet never straddles objects and its padding is at the end
+                        }
+                        ctx->trace.insert(ctx->trace.end(), rec, rec + 6);
+                    }
+                }
+            }
             // group_hist reads 1 B/entry; scatter reads q (4) + ent_obj (1), writes bq (4); memset writes bq (4); scans ~17 B/group
             w->stats.queue_bytes_bin += (uint64_t)n_entries * (1 + 4 + 1) + (uint64_t)n_slots * (4 + 4) + (uint64_t)(n_entries / 64) * 85;
             {
@@ -430,6 +459,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     }
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
+    ctx->trace.clear();
     if (owned.empty()) return RAYN_OK;
     int nw = 1;
     if (ctx->n_workers >= 2 && owned_paths >= ctx->two_worker_min_paths) nw = (int)std::min<size_t>((size_t)std::min(ctx->n_workers, MAX_WORKERS), owned.size());
@@ -694,6 +724,17 @@ int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths) {
     ctx->n_workers = n_workers;
     ctx->two_worker_min_paths = (size_t)min_paths;
     return RAYN_OK;
+}
+int rayn_hip_set_trace_tile(rayn_ctx* ctx, int tile_index) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    ctx->trace_tile = tile_index;
+    return RAYN_OK;
+}
+int64_t rayn_hip_get_trace(const rayn_ctx* ctx, uint32_t* out, uint64_t cap_records) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    const uint64_t n = ctx->trace.size() / 6;
+    if (out) memcpy(out, ctx->trace.data(), (size_t)std::min(n, cap_records) * 24);
+    return (int64_t)n;
 }
 int rayn_hip_fma_policy(void) { return 0; }
 int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy) {

@@ -73,6 +73,17 @@ class Context:
     def set_workers(self, n_workers, min_paths=1 << 22):
         self._chk(self._L.rayn_hip_set_workers(self.h, int(n_workers), int(min_paths)))
 
+    def set_trace_tile(self, tile_index):
+        self._chk(self._L.rayn_hip_set_trace_tile(self.h, int(tile_index)))
+
+    def trace(self):
+        """Packet-order dump of the traced tile: dict of uint32 arrays (depth, obj, px, py, sample, valid)."""
+        n = self._L.rayn_hip_get_trace(self.h, None, 0)
+        buf = np.zeros((max(n, 0), 6), np.uint32)
+        if n > 0:
+            self._L.rayn_hip_get_trace(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return {k: buf[:, i].copy() for i, k in enumerate(("depth", "obj", "px", "py", "sample", "valid"))}
+
     def set_batch_paths(self, n):
         self._chk(self._L.rayn_hip_set_batch_paths(self.h, int(n)))
 

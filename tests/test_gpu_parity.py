@@ -153,6 +153,25 @@ def test_film_parity(gpu_ctx, oracle, name, w, h, samples, bounces, kw):
     assert film_equal_bits(out, ref), f"not bit-exact (L2 {l2})"
 
 
+@pytest.mark.parametrize("name,tile", [("s1", 1), ("s2", 4), ("s1", 5)])
+def test_packet_order_matches_oracle(gpu_ctx, oracle, name, tile):
+    """the GPU's binned queue of a tile, per depth, IS the oracle's packet list (object-major,
+    insertion order, x4 padding) lane for lane — not just the same film."""
+    wd, p = case(name, 48, 48, 2, 4)
+    tabs = _tables(oracle, p)
+    ref = oracle.trace_tile(wd, p, tabs, tile)
+    gpu_ctx.upload_world(wd)
+    gpu_ctx.set_trace_tile(tile)
+    try:
+        gpu_ctx.render_host(p, tabs)
+        got = gpu_ctx.trace()
+    finally:
+        gpu_ctx.set_trace_tile(-1)
+    assert len(ref["depth"]) > 1000 and ref["depth"].max() >= 3
+    for k in ("depth", "obj", "px", "py", "sample", "valid"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
 def test_batching_is_invisible(gpu_ctx, oracle):
     """Splitting the frame into many small batches must not change a single bit."""
     wd, p = case("s1", 64, 48, 2, 3)
