@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Dump / compare the observable state of one render in a documented, toolchain-neutral format (SURVEY.md
+section 8c "Net", row N2): the only route to ever pin this project's oracle against REAL rayn.
+
+  python tools/rayn_dump.py dump OUT_DIR [--scene s2 --w 64 --h 64 --samples 2 --bounces 3 --tile 1 --backend oracle|gpu]
+  python tools/rayn_dump.py compare DIR_A DIR_B
+
+A dump is a directory of raw little-endian arrays + manifest.json:
+  samples_1d.f32   Samples::samples_1d  (spp * sets_1d)            src/sampler.rs:11-15
+  samples_2d.f32   Samples::samples_2d  (2 * spp * sets_2d)
+  scramble.f32     SmallRng::seed_from_u64(x + y*w).gen::<f32>() per pixel, index x + y*w    src/film.rs:460-461
+  fis.f32          FilterImportanceSampler::inverse_cdf (512)      src/filter.rs:187-220
+  color.f32 / alpha.f32 / background.f32 / normal.f32   Film channels after tile_finished, index x + y*w (y = 0 bottom)
+  trace.u32        per-depth packet lanes of tile `tile` in HitStore::process_hits order, 6 u32 per lane:
+                   depth, object id, tile x, tile y, sample, valid         src/hitable.rs:94-134
+INTEGRATION.md shows the ~20 lines of Rust that write the same files from rayn.  `compare` reports, per array, the
+number of differing bit patterns, the max abs difference and (for the film) the max per-pixel L2."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F32 = ["samples_1d", "samples_2d", "scramble", "fis", "color", "alpha", "background", "normal"]
+
+
+def dump(args):
+    from common import case
+    from oracle import oracle_py as O
+    wd, p = case(args.scene, args.w, args.h, args.samples, args.bounces)
+    tabs = O.build_tables(4 * args.samples, args.bounces, p.volume_marches, p.frame, args.w, args.h)
+    if args.backend == "gpu":
+        import rayn_amd
+        ctx = rayn_amd.Context(0)
+        ctx.upload_world(wd)
+        ctx.set_trace_tile(args.tile)
+        film = ctx.render_host(p, tabs)
+        trace = ctx.trace()
+    else:
+        film, _ = O.render(wd, p, tabs)
+        trace = O.trace_tile(wd, p, tabs, args.tile)
+    os.makedirs(args.out, exist_ok=True)
+    arrays = dict(zip(F32[:4], tabs))
+    arrays.update({k: film[k] for k in ("color", "alpha", "background", "normal")})
+    for k, a in arrays.items():
+        np.ascontiguousarray(a, np.float32).tofile(os.path.join(args.out, k + ".f32"))
+    tr = np.stack([trace[k] for k in ("depth", "obj", "px", "py", "sample", "valid")], axis=1).astype(np.uint32)
+    tr.tofile(os.path.join(args.out, "trace.u32"))
+    json.dump({"scene": args.scene, "width": args.w, "height": args.h, "SAMPLES": args.samples, "spp": 4 * args.samples,
+               "max_bounces": args.bounces, "volume_marches": p.volume_marches, "frame": p.frame, "time_range": [p.time_start, p.time_end],
+               "tile": [p.tile_w, p.tile_h], "trace_tile": args.tile, "backend": args.backend}, open(os.path.join(args.out, "manifest.json"), "w"), indent=1)
+    print(f"wrote {args.out}: {len(arrays) + 1} arrays")
+
+
+def compare(args):
+    ma, mb = (json.load(open(os.path.join(d, "manifest.json"))) for d in (args.a, args.b))
+    keys = ("width", "height", "spp", "max_bounces", "volume_marches", "frame")
+    if any(ma[k] != mb[k] for k in keys):
+        print("manifests differ:", {k: (ma[k], mb[k]) for k in keys if ma[k] != mb[k]})
+        return 2
+    worst = 0
+    for name in F32 + ["trace"]:
+        ext, dt = (".u32", np.uint32) if name == "trace" else (".f32", np.float32)
+        a, b = (np.fromfile(os.path.join(d, name + ext), dt) for d in (args.a, args.b))
+        if a.shape != b.shape:
+            print(f"{name:12s} SHAPE {a.shape} vs {b.shape}")
+            worst = 1
+            continue
+        if dt is np.uint32:
+            nd = int((a != b).sum())
+            print(f"{name:12s} {a.size:9d} values, {nd} differ" + (f", first at lane {int(np.argmax(a != b)) // 6}" if nd else ""))
+        else:
+            both_nan = np.isnan(a) & np.isnan(b)
+            nd = int(((a.view(np.uint32) != b.view(np.uint32)) & ~both_nan).sum())
+            mad = float(np.nanmax(np.abs(a.astype(np.float64) - b))) if a.size else 0.0
+            extra = ""
+            if name in ("color", "background", "normal"):
+                extra = f", max per-pixel L2 {float(np.sqrt(((a.astype(np.float64) - b).reshape(-1, 3) ** 2).sum(1)).max()):.3e}"
+            print(f"{name:12s} {a.size:9d} values, {nd} bit patterns differ, max |a-b| {mad:.3e}{extra}")
+        worst = max(worst, 1 if nd else 0)
+    print("IDENTICAL" if worst == 0 else "DIFFERENT")
+    return worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    d = sub.add_parser("dump")
+    d.add_argument("out")
+    d.add_argument("--scene", default="s2")
+    d.add_argument("--w", type=int, default=64)
+    d.add_argument("--h", type=int, default=64)
+    d.add_argument("--samples", type=int, default=2)
+    d.add_argument("--bounces", type=int, default=3)
+    d.add_argument("--tile", type=int, default=1)
+    d.add_argument("--backend", default="oracle", choices=["oracle", "gpu"])
+    c = sub.add_parser("compare")
+    c.add_argument("a")
+    c.add_argument("b")
+    args = ap.parse_args()
+    sys.exit(dump(args) if args.cmd == "dump" else compare(args))
+
+
+if __name__ == "__main__":
+    main()
