@@ -72,6 +72,11 @@ typedef struct {
     float fixed_radius;
     float scale;         /* MandelBox scale, src/sdf.rs:114 */
     float sdf_radius;    /* RAYN_SDF_SPHERE radius */
+    /* RAYN_HITABLE_SPHERE with a closure transform_seq (TR: Fn(f32) -> Vec3, src/sphere.rs:7, src/animation.rs:62-68):
+     * animated != 0 selects the linear closure |t| center + center_vel * t, evaluated — like the reference — at the ray
+     * time of LANE 0 of the packet that calls hit / occluded / get_shading_info. */
+    uint32_t animated;
+    rayn_vec3 center_vel;
     uint32_t _pad;
 } rayn_hitable;
 

@@ -95,8 +95,16 @@ struct MandelBox {
 struct SphereSDF { float radius; }; // sdfu::Sphere::new(radius)
 using SDF = std::variant<MandelBox, SphereSDF>;
 
-struct Sphere { Vec3 transform_seq; float radius; MaterialHandle material;
-                static Sphere new_(Vec3 c, float r, MaterialHandle m) { return Sphere{c, r, m}; } };
+// A time-sequenced Vec3 (src/animation.rs): a constant, or the closure `move |t| base + vel * t`
+struct Sequenced3 {
+    Vec3 base, vel; bool animated = false;
+    Sequenced3() = default;
+    Sequenced3(Vec3 constant) : base(constant) {}
+    static Sequenced3 linear(Vec3 base, Vec3 vel) { Sequenced3 s; s.base = base; s.vel = vel; s.animated = true; return s; }
+};
+
+struct Sphere { Sequenced3 transform_seq; float radius; MaterialHandle material;
+                static Sphere new_(Sequenced3 c, float r, MaterialHandle m) { return Sphere{c, r, m}; } };
 struct TracedSDF { SDF sdf; MaterialHandle material; static TracedSDF new_(SDF s, MaterialHandle m) { return TracedSDF{std::move(s), m}; } };
 using Hitable = std::variant<Sphere, TracedSDF>;
 
@@ -109,14 +117,6 @@ class HitableStore {
 
 // ---- lights, cameras, volume --------------------------------------------------------------------
 struct SphereLight { Vec3 pos; float rad; Srgb emission; static SphereLight new_(Vec3 p, float r, Srgb e) { return SphereLight{p, r, e}; } };
-
-// A time-sequenced Vec3 (src/animation.rs): a constant, or the closure `move |t| base + vel * t`
-struct Sequenced3 {
-    Vec3 base, vel; bool animated = false;
-    Sequenced3() = default;
-    Sequenced3(Vec3 constant) : base(constant) {}
-    static Sequenced3 linear(Vec3 base, Vec3 vel) { Sequenced3 s; s.base = base; s.vel = vel; s.animated = true; return s; }
-};
 
 struct PinholeCamera { Vec2 resolution; float vfov; Sequenced3 origin, at, up;
                        static PinholeCamera new_(Vec2 res, float vfov, Sequenced3 o, Sequenced3 a, Sequenced3 u) { return PinholeCamera{res, vfov, o, a, u}; } };
@@ -151,7 +151,8 @@ struct World { // src/world.rs:7-13
         for (size_t i = 0; i < hitables.len(); i++) {
             rayn_hitable& o = d.hitables[i];
             if (const Sphere* s = std::get_if<Sphere>(&hitables.items[i])) {
-                o.kind = RAYN_HITABLE_SPHERE; o.material = (uint32_t)s->material.idx; o.center = s->transform_seq.pod(); o.radius = s->radius;
+                o.kind = RAYN_HITABLE_SPHERE; o.material = (uint32_t)s->material.idx; o.center = s->transform_seq.base.pod(); o.radius = s->radius;
+                if (s->transform_seq.animated) { o.animated = 1; o.center_vel = s->transform_seq.vel.pod(); }
             } else {
                 const TracedSDF& t = std::get<TracedSDF>(hitables.items[i]);
                 o.kind = RAYN_HITABLE_TRACED_SDF; o.material = (uint32_t)t.material.idx;

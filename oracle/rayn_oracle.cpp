@@ -382,11 +382,19 @@ struct TracedSDF : Hitable {
 /* src/sphere.rs:7-87 (TR = constant Vec3: WSequenced impl returns self, src/animation.rs:27-36,50) */
 struct Sphere : Hitable {
     V3 center; float radius; size_t material;
-    F4 occluded(W3 start, W3 end, F4) const override { /* :24-46 */
+    bool animated = false; V3 center_vel{0, 0, 0};
+    /* WSequenced::sample_at(&self.transform_seq, time): a constant clones itself; the closure |t| center + vel*t is
+     * evaluated at lane 0's time for all four lanes (src/animation.rs:62-68) */
+    W3 sample_at(F4 time) const {
+        if (!animated) return W3::splat(center);
+        float t = time.v[0];
+        return W3::splat(V3{center.x + center_vel.x * t, center.y + center_vel.y * t, center.z + center_vel.z * t});
+    }
+    F4 occluded(W3 start, W3 end, F4 time) const override { /* :24-46 */
         W3 dir = end - start;
         F4 dist = mag(dir);
         dir = dir / dist;
-        W3 origin = W3::splat(center);
+        W3 origin = sample_at(time);
         W3 oc = start - origin;
         F4 b = dot(oc, dir);
         F4 c = mag_sq(oc) - F4(radius * radius);
@@ -400,7 +408,7 @@ struct Sphere : Hitable {
         return merge(valid, F4(0.0f), F4(1.0f));
     }
     F4 hit(const WRay& ray, F4 t_max, const ThresholdFn&) const override { /* :48-71 */
-        W3 origin = W3::splat(center);
+        W3 origin = sample_at(ray.time);
         W3 oc = ray.origin - origin;
         F4 b = dot(oc, ray.dir);
         F4 c = mag_sq(oc) - F4(radius * radius);
@@ -418,7 +426,7 @@ struct Sphere : Hitable {
     }
     ShadingInfo get_shading_info(const WHit& hit, const ThresholdFn&) const override { /* :73-86 */
         W3 point = hit.point();
-        W3 origin = W3::splat(center);
+        W3 origin = sample_at(hit.ray.time);
         W3 normal = normalized(point - origin);
         return ShadingInfo{material, WShadingPoint::make(hit, point, F4(0.0f), normal)};
     }
@@ -676,6 +684,7 @@ struct World {
             if (h.kind == RAYN_HITABLE_SPHERE) {
                 auto s = std::make_unique<Sphere>();
                 s->center = V3{h.center.x, h.center.y, h.center.z}; s->radius = h.radius; s->material = h.material;
+                s->animated = h.animated != 0; s->center_vel = V3{h.center_vel.x, h.center_vel.y, h.center_vel.z};
                 hitables.push_back(std::move(s));
             } else {
                 auto t = std::make_unique<TracedSDF>();

@@ -270,8 +270,11 @@ RD f3 sdf_normal(const DHitable& h, f3 p, float eps, uint32_t& evals) {
 }
 
 // ---- Sphere (src/sphere.rs:23-71) ------------------------------------------------------------------
-RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max) {
-    f3 oc = o - h.center;
+// Sphere centre at the packet's lane-0 time t0 (closure transform_seq, src/animation.rs:62-68); constants ignore t0
+RD f3 sphere_center(const DHitable& h, float t0) { return h.animated ? h.center + h.center_vel * t0 : h.center; }
+
+RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max, float t0) {
+    f3 oc = o - sphere_center(h, t0);
     float b = dot(oc, d);
     float c = mag_sq(oc) - h.radius_sq;
     float descrim = b * b - c;
@@ -286,11 +289,11 @@ RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max) {
     float t = take_t1 ? t1 : t2;
     return (t1_valid || t2_valid) ? t : 3.40282347e+38f;
 }
-RD float sphere_occluded(const DHitable& h, f3 start, f3 end) {
+RD float sphere_occluded(const DHitable& h, f3 start, f3 end, float t0) {
     f3 dir = end - start;
     float dist = mag(dir);
     dir = dir / dist;
-    f3 oc = start - h.center;
+    f3 oc = start - sphere_center(h, t0);
     float b = dot(oc, dir);
     float c = mag_sq(oc) - h.radius_sq;
     float descrim = b * b - c;
@@ -306,12 +309,12 @@ RD float sphere_occluded(const DHitable& h, f3 start, f3 end) {
 
 // HitableStore::add_hits fold, src/hitable.rs:177-198: closest-so-far is the next t_max.
 template <bool COUNT>
-RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float* out_t, uint32_t* out_obj, uint32_t& evals) {
+RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float t0, float* out_t, uint32_t* out_obj, uint32_t& evals) {
     float closest = sc.t_max;
     uint32_t id = OBJ_NONE;
     for (uint32_t k = 0; k < sc.n_hitables; k++) {
         const DHitable& h = sc.h[k];
-        float t = h.kind == RAYN_HITABLE_SPHERE ? sphere_hit(h, o, d, closest) : sdf_hit<COUNT>(sc, h, o, d, closest, th, evals);
+        float t = h.kind == RAYN_HITABLE_SPHERE ? sphere_hit(h, o, d, closest, t0) : sdf_hit<COUNT>(sc, h, o, d, closest, th, evals);
         if (t < closest) { closest = t; id = k; }
     }
     *out_t = closest;
@@ -320,9 +323,9 @@ RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float* out_t, u
 // HitableStore::test_occluded, src/hitable.rs:164-168.  Every factor is exactly 0 or 1, so the
 // product is order-independent: analytic spheres first, SDF marches only if still visible.
 template <bool COUNT>
-RD float test_occluded(const DScene& sc, f3 start, f3 end, uint32_t& evals) {
+RD float test_occluded(const DScene& sc, f3 start, f3 end, float t0, uint32_t& evals) {
     for (uint32_t k = 0; k < sc.n_hitables; k++)
-        if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], start, end) == 0.0f) return 0.0f;
+        if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], start, end, t0) == 0.0f) return 0.0f;
     for (uint32_t k = 0; k < sc.n_hitables; k++)
         if (sc.h[k].kind != RAYN_HITABLE_SPHERE && sdf_occluded<COUNT>(sc, sc.h[k], start, end, evals) == 0.0f) return 0.0f;
     return 1.0f;

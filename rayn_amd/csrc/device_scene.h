@@ -13,7 +13,8 @@ struct DHitable {
     uint32_t kind, material, sdf_kind, iterations;
     f3 center; float radius_sq;           // Sphere: f32x4::from(radius*radius), src/sphere.rs:31,52
     float box_l, min_rad_sq, fixed_rad_sq, scale; // MandelBox (src/sdf.rs:114-122,151-158,172-179)
-    float sdf_radius; uint32_t fast_div; uint32_t _pad[2];
+    float sdf_radius; uint32_t fast_div; uint32_t animated; uint32_t _pad;
+    f3 center_vel; float _pad2;
 };
 struct DMaterial { uint32_t kind, receives_light; float exponent, _pad; f3 a; float _p1; f3 b; float _p2; };
 struct DLight { f3 pos; float rad; f3 emission; float _pad; };
@@ -30,6 +31,7 @@ struct DScene {
     DLight l[RAYN_MAX_LIGHTS];
     DCamera cam;
     uint32_t has_scatter, has_extinct; float rho_s, rho_t;
+    uint32_t anim_spheres, _pad_a[3]; // any Sphere with a time-sequenced centre
     // frame constants
     uint32_t width, height, spp, max_bounces, vm, max_marches, max_vis_marches, n1, n2;
     float time_start, time_range, detail_scale, t_max, ndc_x, ndc_y;

@@ -79,6 +79,15 @@ __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, 
 // Writes t + object into the pool, the object per entry, and the per-group object histogram that
 // the bin scan consumes (wave ballot, no atomics).
 // ------------------------------------------------------------------------------------------------
+// Ray time of lane 0 of the reference packet a queue entry belongs to (queue chunks of 4; a tile's segment starts at a
+// multiple of 64 and is padded only at its end, like the reference's spawned_wrays, src/film.rs:608-625).  Only needed
+// when a Sphere centre is time-sequenced.
+RD float packet_time(const DScene& sc, const uint32_t* __restrict__ q, const Pool& pool, uint32_t ent) {
+    if (!sc.anim_spheres) return 0.0f;
+    const uint32_t P0 = q[ent & ~3u];
+    return P0 == INVALID ? dm_nanf() : pool.col1[P0].w;
+}
+
 // Persistent waves: march lengths vary 1..257 per ray, so a thread-per-ray launch idles most lanes.
 // Here every lane owns a small state machine; a lane whose ray is finished immediately takes the
 // next queue entry (wave-local chunk of 256 entries, refilled with ONE atomic per chunk), so every
@@ -101,13 +110,13 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
     bool has = false, first = false, nan = false;
     uint32_t ent = 0, P = 0, k = 0, id = OBJ_NONE, m = 0, evals = 0, sbits = 0;
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
-    float closest = 0.0f, t = 0.0f;
+    float closest = 0.0f, t = 0.0f, t0 = 0.0f;
     // fold over the hitables (src/hitable.rs:177-198) up to the next TracedSDF; finish the ray at the end
     auto advance = [&]() {
         while (k < nh) {
             const DHitable& hh = sc.h[k];
             if (hh.kind != RAYN_HITABLE_SPHERE) { first = true; return; }
-            float ts = sphere_hit(hh, o, d, closest);
+            float ts = sphere_hit(hh, o, d, closest, t0);
             if (ts < closest) { closest = ts; id = k; }
             k++;
         }
@@ -146,6 +155,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
                         o = f3{g0.x, g0.y, g0.z};
                         d = f3{g0.w, g1.x, g1.y};
                         sbits = __float_as_uint(g1.w);
+                        t0 = packet_time(sc, q, pool, ent);
                         closest = sc.t_max; id = OBJ_NONE; k = 0; has = true;
                         advance();
                         marching = has;
@@ -242,16 +252,17 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
                         const float2 g1 = *(const float2*)(&pool.geo1[n_P].x);
                         n_o = f3{g0.x, g0.y, g0.z};
                         n_d = f3{g0.w, g1.x, g1.y};
+                        const float t0 = packet_time(sc, q, pool, n_ent);
                         float closest = sc.t_max;
                         uint32_t id = OBJ_NONE;
                         for (uint32_t k = 0; k < ks; k++) { // spheres before the SDF: the true fold
-                            float ts = sphere_hit(sc.h[k], n_o, n_d, closest);
+                            float ts = sphere_hit(sc.h[k], n_o, n_d, closest, t0);
                             if (ts < closest) { closest = ts; id = k; }
                         }
                         n_pre = closest;
                         uint32_t idp = OBJ_NONE;
                         for (uint32_t k = ks + 1; k < nh; k++) { // spheres after it: candidates (see header)
-                            float ts = sphere_hit(sc.h[k], n_o, n_d, closest);
+                            float ts = sphere_hit(sc.h[k], n_o, n_d, closest, t0);
                             if (ts < closest) { closest = ts; idp = k; }
                         }
                         n_post = closest;
@@ -501,6 +512,8 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
         g0 = pool.geo0[P]; g1 = pool.geo1[P]; c0 = pool.col0[P]; c1 = pool.col1[P];
         sample = __float_as_uint(g1.w) >> 8; pix = __float_as_uint(c1.z); scr = scramble[pix];
     }
+    // lane 0 of the packet supplies the time of closure-sequenced sphere centres (get_shading_info, occluded)
+    const float t0 = sc.anim_spheres ? __shfl(c1.w, (int)(lane & ~3u)) : 0.0f;
     // this lane's random numbers of this depth (raw table values; the pixel scramble is added per use)
     const float4* rec = tab.rec + (size_t)(depth * spp + sample) * tab.rec_stride;
     const float4 r1d = rec[0];
@@ -539,7 +552,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     // analytic spheres of test_occluded (every factor is exactly 0 or 1 -> order independent)
     auto spheres_visible = [&](f3 a, f3 b) {
         for (uint32_t k = 0; k < sc.n_hitables; k++)
-            if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], a, b) == 0.0f) return false;
+            if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], a, b, t0) == 0.0f) return false;
         return true;
     };
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0}, rad = f3{0, 0, 0}, thr = f3{0, 0, 0}, point = f3{0, 0, 0}, normal = f3{0, 0, 1};
@@ -556,7 +569,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
         const DHitable& h = sc.h[obj];
         point = muladd3(d, t, o); // WHit::point -> Ray::point_at
         if (h.kind == RAYN_HITABLE_SPHERE) { // src/sphere.rs:73-86
-            normal = normalized(point - h.center);
+            normal = normalized(point - sphere_center(h, t0));
             offset_by = 0.0f;
         } else { // src/sdf.rs:85-101
             Thr th = make_thr(sc, depth);
@@ -1041,7 +1054,7 @@ __global__ void k_probe_closest(const DScene* __restrict__ scp, uint32_t depth, 
     uint32_t ev = 0, obj;
     float t;
     closest_hit<false>(*scp, f3{org[3 * i], org[3 * i + 1], org[3 * i + 2]}, f3{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]},
-                       make_thr(*scp, depth), &t, &obj, ev);
+                       make_thr(*scp, depth), 0.0f, &t, &obj, ev);
     out_t[i] = t;
     out_obj[i] = obj == OBJ_NONE ? INVALID : obj;
 }
@@ -1049,7 +1062,7 @@ __global__ void k_probe_occluded(const DScene* __restrict__ scp, const float* __
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t ev = 0;
-    out[i] = test_occluded<false>(*scp, f3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, f3{b[3 * i], b[3 * i + 1], b[3 * i + 2]}, ev);
+    out[i] = test_occluded<false>(*scp, f3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, f3{b[3 * i], b[3 * i + 1], b[3 * i + 2]}, 0.0f, ev);
 }
 __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

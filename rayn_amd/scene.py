@@ -235,7 +235,12 @@ class World:
             o.material = h.material
             if isinstance(h, Sphere):
                 o.kind = _abi.HITABLE_SPHERE
-                put(o.center, h.transform_seq)
+                if isinstance(h.transform_seq, Linear):
+                    put(o.center, h.transform_seq.base)
+                    put(o.center_vel, h.transform_seq.vel)
+                    o.animated = 1
+                else:
+                    put(o.center, h.transform_seq)
                 o.radius = h.radius
             elif isinstance(h, TracedSDF):
                 o.kind = _abi.HITABLE_TRACED_SDF

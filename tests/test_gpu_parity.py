@@ -272,6 +272,12 @@ def _custom_world(kind, res):
         world.cameras = R.CameraStore()
         cam_h = world.cameras.add_camera(R.ThinLensCamera(resf, 50.0, 0.05, origin, R.Linear(R.vec3(0, 0, 0), R.vec3(1.0, 2.0, 0.0)), R.vec3(0, 1, 0),
                                                           R.Linear(R.vec3(0.2, 0.1, 0.9), R.vec3(0.0, 0.0, -4.0))))
+    elif kind == "anim_spheres":  # closure transform_seq on Spheres: motion-blurred light proxies + a moving diffuse ball
+        for i in (2, 3, 4):
+            s = world.hitables[i]
+            s.transform_seq = R.Linear(s.transform_seq, R.vec3(3.0, -2.0, 1.5))
+        ball = world.materials.add_material(R.Lambertian(R.Srgb(0.7, 0.6, 0.5)))
+        world.hitables.push(R.Sphere(R.Linear(R.vec3(-1.6, -0.4, 1.9), R.vec3(9.0, 3.0, 0.0)), 0.3, ball))
     elif kind == "lambertian":
         world.materials[1] = R.Lambertian(R.Srgb(0.6, 0.3, 0.2))
     elif kind == "no_lights":
@@ -289,7 +295,7 @@ def _custom_world(kind, res):
     return world.to_desc(cam_h)
 
 
-@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere"])
+@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "anim_spheres", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere"])
 def test_closed_set_parity(gpu_ctx, oracle, kind):
     from rayn_amd import params as P
     w, h, samples, bounces = 40, 32, 2, 4
