@@ -153,7 +153,9 @@ typedef struct {
     float sdf_detail_scale;   /* SDF_DETAIL_SCALE, src/setup.rs:37 */
     float world_radius;       /* WORLD_RADIUS, src/setup.rs:33 */
     /* multi-GPU film partition (no reference counterpart; tiles are independent, src/film.rs:439-627):
-     * this call renders tiles k with k % tile_step == tile_first, k in the reference's tile order. */
+     * this call renders the tiles k (reference tile order) with (k + k / tile_step) % tile_step == tile_first: every run of
+     * tile_step consecutive tiles holds each owner once, and the assignment rotates from run to run so that no owner is
+     * locked to a fixed lattice of image rows (measured: the plain k % 8 lattice left one of 8 ranks 7 % slower). */
     uint32_t tile_first, tile_step;
 } rayn_frame_params;
 
@@ -231,8 +233,9 @@ int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals);
 /* out[0] k_extend (closest-hit marches), out[1] k_shade_setup (normal estimation), out[2] k_shadow (NEE visibility) */
 int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
 /* A frame's tiles are dealt to up to two workers (host thread + HIP stream + own device memory each) so that one
- * worker's HBM-bound kernels and readbacks run underneath the other's VALU-bound marches.  n_workers 1|2 (default 2);
- * frames with fewer than min_paths camera paths use one worker (default 2^22). */
+ * worker's HBM-bound kernels and readbacks run underneath the other's VALU-bound marches.  n_workers 1..4 (default 2).
+ * A further worker is only used while every worker still gets full-size batches and the call owns >= min_paths camera
+ * paths (default 2^22); min_paths = 0 forces n_workers (tests). */
 int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths);
 /* upper limit of the path-pool capacity per worker and batch of tiles (default 2^27 paths, ~45 GB of HBM per worker for a
  * scene without volume); the effective size is also capped so that all workers together use <= 60 % of the free HBM. */

@@ -1071,7 +1071,7 @@ void oracle_build_scramble(uint32_t w, uint32_t h, float* out) {
 void oracle_build_fis_table(uint32_t kind, float radius, float* out) { build_fis(kind, radius, out); }
 uint32_t oracle_tile_count(uint32_t w, uint32_t h, uint32_t tw, uint32_t th) { return (uint32_t)build_tiles(w, h, tw, th).size(); }
 
-/* Film::render_frame_into.  tile_subset == NULL renders every tile k with k % tile_step == tile_first
+/* Film::render_frame_into.  tile_subset == NULL renders every tile k with (k + k / tile_step) % tile_step == tile_first
  * (all tiles for 0/1); otherwise exactly the listed tile indices.  Untouched pixels keep their value. */
 int oracle_render_frame(const rayn_world_desc* wd, const rayn_frame_params* p, const float* s1d, const float* s2d,
                         const float* scramble, const float* fis, float* out_color, float* out_alpha,
@@ -1085,7 +1085,7 @@ int oracle_render_frame(const rayn_world_desc* wd, const rayn_frame_params* p, c
     std::vector<TileBounds> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
     std::vector<uint32_t> todo;
     if (tile_subset) todo.assign(tile_subset, tile_subset + n_subset);
-    else { uint32_t step = p->tile_step ? p->tile_step : 1; for (uint32_t k = p->tile_first; k < tiles.size(); k += step) todo.push_back(k); }
+    else { uint32_t step = p->tile_step ? p->tile_step : 1; for (uint32_t k = 0; k < tiles.size(); k++) if ((k + k / step) % step == p->tile_first) todo.push_back(k); }
     FilmOut film{out_color, out_alpha, out_background, out_normal};
     std::atomic<size_t> next{0}; std::atomic<uint64_t> evals{0}, n_paths{0}, n_segments{0}, n_packets{0};
     auto worker = [&]() {

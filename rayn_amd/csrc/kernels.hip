@@ -515,9 +515,15 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     // lane 0 of the packet supplies the time of closure-sequenced sphere centres (get_shading_info, occluded)
     const float t0 = sc.anim_spheres ? __shfl(c1.w, (int)(lane & ~3u)) : 0.0f;
     // this lane's random numbers of this depth (raw table values; the pixel scramble is added per use)
+    // Random numbers (and light picks) are only consumed by packets of light-receiving objects, or by every segment when
+    // the volume scatters; bins are object-major, so whole waves of sky / emissive hits skip the table fetch.
+    const bool recv_l = valid && sc.m[sc.h[__float_as_uint(g1.w) & 0xFFu].material].receives_light != 0;
+    const bool pk_recv = __shfl((int)recv_l, (int)(lane & ~3u)) != 0; // lane 0 of a bin packet is always a real hit
+    const bool wave_needs_samples = sc.has_scatter || __ballot(pk_recv) != 0;
     const float4* rec = tab.rec + (size_t)(depth * spp + sample) * tab.rec_stride;
-    const float4 r1d = rec[0];
-    const float r1d4 = rec[1].x;
+    float4 r1d = make_float4(0, 0, 0, 0);
+    float r1d4 = 0.0f;
+    if (wave_needs_samples) { r1d = rec[0]; r1d4 = rec[1].x; }
     auto s1 = [&](uint32_t k) { // samples_1d[k] of this depth, src/film.rs:568-574 + Samples::sample_1d
         const float raw = k == 0 ? r1d.x : (k == 1 ? r1d.y : (k == 2 ? r1d.z : (k == 3 ? r1d.w : r1d4)));
         return dm_fractf(raw + scr);
@@ -526,7 +532,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     // 4 bits each (n_lights <= 16) so the rolled loops below need no register arrays.
     uint32_t surf_picks = 0;
     unsigned long long vol_picks = 0;
-    if (nl > 0) {
+    if (nl > 0 && wave_needs_samples) {
         const uint32_t base = lane & ~3u;
         for (uint32_t k = 0; k < 1 + VM; k++) {
             uint32_t mine = light_index(s1(k), nl);

@@ -450,7 +450,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     std::vector<TileRect> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
     std::vector<BatchTile> owned;
     size_t owned_paths = 0;
-    for (uint32_t k = p->tile_first; k < tiles.size(); k += step) {
+    for (uint32_t k = 0; k < tiles.size(); k++) {
+        if ((k + k / step) % step != p->tile_first) continue; // owner of tile k: rotates by one every 'step' tiles (rayn_hip.h)
         const TileRect& t = tiles[k];
         uint32_t ew = t.x1 - t.x0, eh = t.y1 - t.y0;
         if (!ew || !eh) continue;
@@ -463,10 +464,6 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
     ctx->trace.clear();
     if (owned.empty()) return RAYN_OK;
-    int nw = 1;
-    if (ctx->n_workers >= 2 && owned_paths >= ctx->two_worker_min_paths) nw = (int)std::min<size_t>((size_t)std::min(ctx->n_workers, MAX_WORKERS), owned.size());
-    std::vector<BatchTile> share[MAX_WORKERS];
-    for (size_t i = 0; i < owned.size(); i++) share[i % nw].push_back(owned[i]);
 
     // ---- shared, read-only state: scene, tables, packed sample records
     const uint32_t rec_stride = (8 + hs.n2) / 4, rec_depths = p->max_bounces + 1;
@@ -487,15 +484,26 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     F.d_scr = d_scr; F.d_color = d_color; F.d_alpha = d_alpha; F.d_bg = d_bg; F.d_normal = d_normal;
     F.NS = 4 + (ctx->world.has_scattering ? 4 * p->volume_marches : 0); // NEE samples per shading point
     F.count = ctx->counting; F.profiling = ctx->profiling;
-    {   // bigger batches = fewer launches and tails (measured 2^25 -> 2^27 paths: -9 % frame time): size them for the HBM
-        // that is actually free, at most 60 % of it across the workers (the rest stays for the caller: film, tables, torch)
+    // Batch size and worker count.  Bigger batches = fewer launches and tails (2^25 -> 2^27 paths: -9 % frame time), so
+    // they are sized for the HBM that is actually free: at most 60 % of it across the workers (the rest stays with the
+    // caller: film, tables, torch).  A second/third worker only pays when every worker still gets full-size batches
+    // (measured on config 2: whole frame +4 %, a quarter of the frame -4 %, an eighth -10 %).
+    int nw = 1;
+    {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         for (const Worker& w : ctx->workers) free_b += w.arena.cap;
         const size_t per_path = 101 + 53 * (size_t)F.NS + 4 * ((size_t)F.NS - 3) + 17; // pool + queues + NEE records + shadow segments
-        const size_t fit = (size_t)(0.6 * (double)free_b) / (size_t)nw / per_path;
-        F.batch_paths = std::max<size_t>(4096, std::min(ctx->batch_paths, fit));
+        const size_t budget_paths = (size_t)(0.6 * (double)free_b) / per_path;
+        const int max_w = std::min(std::min(ctx->n_workers, MAX_WORKERS), (int)std::min<size_t>(owned.size(), MAX_WORKERS));
+        for (int c = std::max(max_w, 1); c >= 1; c--) {
+            const size_t cap = std::max<size_t>(4096, std::min(ctx->batch_paths, budget_paths / (size_t)c));
+            if (c == 1 || (owned_paths >= ctx->two_worker_min_paths && owned_paths >= (size_t)c * cap) ||
+                (ctx->two_worker_min_paths == 0)) { nw = c; F.batch_paths = cap; break; }
+        }
     }
+    std::vector<BatchTile> share[MAX_WORKERS];
+    for (size_t i = 0; i < owned.size(); i++) share[i % nw].push_back(owned[i]);
     // fork: the worker streams start after everything already queued on the caller's stream
     HIPCHK(hipEventRecord(ctx->ev_fork, stream));
     HIPCHK(hipStreamSynchronize(stream)); // F.hs is on this stack frame: make sure the scene copy has been consumed

@@ -1,6 +1,6 @@
 """Multi-GPU film partition: one process per GPU, whole 16x16 tiles dealt round-robin to ranks
-(tile k belongs to rank k % world — tiles are fully independent, src/film.rs:439-627, and their cost
-is very uneven, so interleaving balances the load), and ONE gather of each rank's owned pixels to
+(tile k belongs to rank (k + k // world) % world — tiles are fully independent, src/film.rs:439-627, and their
+cost is very uneven, so ranks are interleaved and the interleave rotates every `world` tiles), and ONE gather of each rank's owned pixels to
 rank 0 at frame end (RCCL over xGMI with backend "nccl"; gloo on CPU in the tests).  No other
 collective touches the data path."""
 import numpy as np
@@ -17,7 +17,7 @@ def owned_pixels(width, height, tile_w, tile_h, rank, world):
     """Film pixel indices (x + y*width) of the tiles rank owns, in tile order."""
     idx = []
     for k, (x0, y0, x1, y1) in enumerate(tile_rects(width, height, tile_w, tile_h)):
-        if k % world != rank or x1 <= x0 or y1 <= y0:
+        if (k + k // world) % world != rank or x1 <= x0 or y1 <= y0:
             continue
         xs, ys = np.meshgrid(np.arange(x0, x1), np.arange(y0, y1), indexing="ij")
         idx.append((xs + ys * width).reshape(-1))
