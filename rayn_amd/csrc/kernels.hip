@@ -94,6 +94,7 @@ RD float packet_time(const DScene& sc, const uint32_t* __restrict__ q, const Poo
 // loop iteration evaluates the SDF on (almost) all 64 lanes.  Results are written by entry/pool
 // index, so the fetch order never influences the output.
 constexpr uint32_t CHUNK = 256;
+constexpr uint32_t ENDGAME_ENTRIES = 256 * 32 * 64; // about one ray per resident lane of the chip
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, uint32_t depth, const uint32_t* __restrict__ q,
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     const DHitable h = sc.h[ks]; // uniform copy
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
-    bool exhausted = false;
+    bool exhausted = false, endgame = false;
     // current ray
     bool c_has = false, first = false, nan = false;
     uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0, evals = 0;
@@ -230,9 +231,11 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     for (;;) {
         const uint64_t lack = __ballot(!n_has);
         const uint64_t idle = __ballot(!c_has && !n_has);
-        if (!exhausted && ((uint32_t)__popcll(lack) >= PREFETCH_MIN || (uint32_t)__popcll(idle) >= 4u)) {
+        // endgame: once the queue is nearly drained no more spare rays are hoarded (a spare held by a lane that is still
+        // inside a long march would wait while other lanes idle) - idle lanes then fetch one ray at a time
+        if (!exhausted && (endgame ? idle != 0 : ((uint32_t)__popcll(lack) >= PREFETCH_MIN || (uint32_t)__popcll(idle) >= 4u))) {
             for (;;) {
-                const uint64_t need = __ballot(!n_has);
+                const uint64_t need = endgame ? __ballot(!n_has && !c_has) : __ballot(!n_has);
                 if (need == 0) break;
                 if (cur == end) {
                     uint32_t base = 0;
@@ -241,9 +244,10 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
                     if (base >= n_entries) { exhausted = true; break; }
                     cur = base;
                     end = min(base + CHUNK, n_entries);
+                    endgame = n_entries - base < ENDGAME_ENTRIES;
                 }
                 const uint32_t rank = mbcnt(need), avail = end - cur;
-                if (!n_has && rank < avail) {
+                if ((need >> lane) & 1ull) if (rank < avail) {
                     n_ent = cur + rank;
                     n_P = q[n_ent];
                     if (n_P == INVALID) ent_obj[n_ent] = (uint8_t)OBJ_NONE;
@@ -818,7 +822,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     const DHitable h = sc.h[ks];
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
-    bool exhausted = false;
+    bool exhausted = false, endgame = false;
     bool c_has = false, first = false, nan = false, n_has = false;
     uint32_t ref = 0, n_ref = 0, m = 0, evals = 0;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
@@ -826,9 +830,11 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     for (;;) {
         const uint64_t lack = __ballot(!n_has);
         const uint64_t idle = __ballot(!c_has && !n_has);
-        if (!exhausted && ((uint32_t)__popcll(lack) >= PREFETCH_MIN || (uint32_t)__popcll(idle) >= 4u)) {
+        // endgame: once the queue is nearly drained no more spare rays are hoarded (a spare held by a lane that is still
+        // inside a long march would wait while other lanes idle) - idle lanes then fetch one ray at a time
+        if (!exhausted && (endgame ? idle != 0 : ((uint32_t)__popcll(lack) >= PREFETCH_MIN || (uint32_t)__popcll(idle) >= 4u))) {
             for (;;) {
-                const uint64_t need = __ballot(!n_has);
+                const uint64_t need = endgame ? __ballot(!n_has && !c_has) : __ballot(!n_has);
                 if (need == 0) break;
                 if (cur == end) {
                     uint32_t base = 0;
@@ -837,9 +843,10 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                     if (base >= n_jobs) { exhausted = true; break; }
                     cur = base;
                     end = min(base + CHUNK, n_jobs);
+                    endgame = n_jobs - base < ENDGAME_ENTRIES;
                 }
                 const uint32_t rank = mbcnt(need), avail = end - cur;
-                if (!n_has && rank < avail) {
+                if ((need >> lane) & 1ull) if (rank < avail) {
                     n_ref = nee.job_ref[cur + rank];
                     const float4 ja = nee.job_geo[2 * (size_t)n_ref], jb = nee.job_geo[2 * (size_t)n_ref + 1];
                     n_start = f3{ja.x, ja.y, ja.z};
