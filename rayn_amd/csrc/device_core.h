@@ -179,12 +179,12 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
         const float frs_eff = mrs <= frs ? frs : -1.0f;
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
-#define RAYN_FOLD_BODY(DIV)                                                                   \
+#define RAYN_FOLD_BODY(DIV, BOX)                                                                  \
         for (uint32_t i = 0; i < h.iterations; i++) {                                         \
             /* box_fold: clamped(-l, l).mul_add(2, -p) */                                     \
-            p.x = muladd(__builtin_amdgcn_fmed3f(p.x, nl, l), 2.0f, -p.x);                    \
-            p.y = muladd(__builtin_amdgcn_fmed3f(p.y, nl, l), 2.0f, -p.y);                    \
-            p.z = muladd(__builtin_amdgcn_fmed3f(p.z, nl, l), 2.0f, -p.z);                    \
+            p.x = BOX(__builtin_amdgcn_fmed3f(p.x, nl, l), p.x);                              \
+            p.y = BOX(__builtin_amdgcn_fmed3f(p.y, nl, l), p.y);                              \
+            p.z = BOX(__builtin_amdgcn_fmed3f(p.z, nl, l), p.z);                              \
             /* sphere_fold: mul = max(1, R2 / max(r2min, r2)).  For r2 >= R2 (and for NaN) the quotient  \
                is <= 1, mul is exactly 1 and the two multiplies are identities, so the whole block is     \
                skipped - the compiler branches around it when no lane of the wave needs it, which is the  \
@@ -202,9 +202,14 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
             dr = muladd(-dr, s, 1.0f);                                                        \
         }
 #define RAYN_DIV_IEEE(a, b) ((a) / (b))
-        if (h.fast_div) { RAYN_FOLD_BODY(div_nr) } else { RAYN_FOLD_BODY(RAYN_DIV_IEEE) }
+#define RAYN_BOX_REF(c, q) muladd(c, 2.0f, -(q))
+        // |c| <= |l| <= 2^60: the product 2c is exact, so ONE rounding (fma) == the reference's two (mul, add)
+#define RAYN_BOX_FMA(c, q) __builtin_fmaf(c, 2.0f, -(q))
+        if (h.fast_div) { RAYN_FOLD_BODY(div_nr, RAYN_BOX_FMA) } else { RAYN_FOLD_BODY(RAYN_DIV_IEEE, RAYN_BOX_REF) }
 #undef RAYN_FOLD_BODY
 #undef RAYN_DIV_IEEE
+#undef RAYN_BOX_REF
+#undef RAYN_BOX_FMA
         return mag(p) / __builtin_fabsf(dr);
     }
     if (h.sdf_kind == RAYN_SDF_MANDELBULB) return mandelbulb_dist(p, h.iterations);

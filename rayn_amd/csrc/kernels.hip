@@ -938,26 +938,29 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
 // the pixel's spp paths by termination key in LDS (bitonic) and three lanes (r,g,b) accumulate them
 // sequentially.  Alpha/WorldNormal are depth-0 samples, ordered (object, sample).
 // ------------------------------------------------------------------------------------------------
+// Keys carry their payload (the sample index) in the low bits, so the network moves one word per element.
+// Each lane owns whole compare-exchange pairs (two per trip, loads issued together): one LDS round trip per
+// step instead of one per element.
 template <typename K>
-RD void bitonic_sort_lds(K* key, uint32_t* val, uint32_t n) {
+RD void bitonic_sort_lds(K* key, uint32_t n) {
+    const uint32_t half = n >> 1;
     for (uint32_t k = 2; k <= n; k <<= 1)
         for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-                uint32_t l = i ^ jj;
-                if (l > i) {
-                    bool up = (i & k) == 0;
-                    K a = key[i], b = key[l];
-                    if ((a > b) == up) {
-                        key[i] = b; key[l] = a;
-                        uint32_t t = val[i]; val[i] = val[l]; val[l] = t;
-                    }
-                }
+            const uint32_t lo = jj - 1;
+            for (uint32_t p0 = threadIdx.x; p0 < half; p0 += 128) {
+                const uint32_t p1 = p0 + 64;
+                const bool two = p1 < half;
+                const uint32_t i0 = ((p0 & ~lo) << 1) | (p0 & lo), l0 = i0 | jj;
+                const uint32_t i1 = two ? ((p1 & ~lo) << 1) | (p1 & lo) : i0, l1 = i1 | jj;
+                const K a0 = key[i0], b0 = key[l0], a1 = key[i1], b1 = key[l1];
+                if ((a0 > b0) == ((i0 & k) == 0)) { key[i0] = b0; key[l0] = a0; }
+                if (two && (a1 > b1) == ((i1 & k) == 0)) { key[i1] = b1; key[l1] = a1; }
             }
             __syncthreads();
         }
 }
 
-// true when key[0..n) is already non-decreasing (wave-wide; n_sort is a power of two >= 1)
+// true when key[0..n) is already non-decreasing (wave-wide; n is a power of two >= 8)
 template <typename K>
 RD bool is_sorted_lds(const K* key, uint32_t n) {
     bool ok = true;
@@ -965,14 +968,35 @@ RD bool is_sorted_lds(const K* key, uint32_t n) {
     return __ballot(!ok) == 0;
 }
 
+// number of leading entries below `none` in a sorted key array (wave-wide)
+template <typename K>
+RD uint32_t count_valid_lds(const K* key, uint32_t n, K none) {
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) c += (uint32_t)__popcll(__ballot(key[i] != none));
+    return c;
+}
+
+// serial float sum of src[0..cnt) in index order (one lane = one channel); loads are issued eight at a time
+RD float serial_sum(const float* src, uint32_t cnt) {
+    float a = 0.0f;
+    uint32_t e = 0;
+    for (; e + 8 <= cnt; e += 8) {
+        const float4 v0 = *(const float4*)(src + e), v1 = *(const float4*)(src + e + 4);
+        a += v0.x; a += v0.y; a += v0.z; a += v0.w;
+        a += v1.x; a += v1.y; a += v1.z; a += v1.w;
+    }
+    for (; e < cnt; e++) a += src[e];
+    return a;
+}
+
 __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
                                                  float* __restrict__ out_color, float* __restrict__ out_alpha,
                                                  float* __restrict__ out_background, float* __restrict__ out_normal, uint32_t n_sort) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem64[];
-    unsigned long long* key = smem64;           // [n_sort]
-    uint32_t* val = (uint32_t*)(smem64 + n_sort); // [n_sort]
-    uint32_t* key32 = val + n_sort;             // [n_sort]
-    float* stage = (float*)(key32 + n_sort);    // [3][n_sort] values in accumulation order
+    unsigned long long* key = smem64;              // [n_sort] depth:7 | slot:32 | background:1 | sample:12
+    uint8_t* flg = (uint8_t*)(smem64 + n_sort);    // [n_sort] 1 = Background sample (4 bytes per entry reserved)
+    uint32_t* key32 = (uint32_t*)flg + n_sort;     // [n_sort] object:16 | sample:16
+    float* stage = (float*)(key32 + n_sort);       // [3][n_sort] values in accumulation order
     constexpr unsigned long long NOKEY = ~0ull;
     const DScene& sc = *scp;
     const DTile tile = tiles[blockIdx.y];
@@ -988,30 +1012,39 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
         unsigned long long k = NOKEY;
         if (i < spp) {
             const uint32_t info = pool.term_info[P0 + i];
-            if (info != TERM_NONE) k = ((unsigned long long)(info & 0x7Fu) << 32) | pool.term_key[P0 + i];
+            if (info != TERM_NONE)
+                k = ((unsigned long long)(info & 0x7Fu) << 45) | ((unsigned long long)pool.term_key[P0 + i] << 13) | ((info >> 7) << 12) | i;
         }
         key[i] = k;
-        val[i] = i;
     }
     __syncthreads();
-    if (!is_sorted_lds(key, n_sort)) bitonic_sort_lds(key, val, n_sort); // sky-only pixels arrive sorted
-    // all lanes stage the values in accumulation order; Background samples carry the sign bit of val
-    for (uint32_t e = threadIdx.x; e < spp; e += 64) {
-        if (key[e] != NOKEY) {
-            const uint32_t P = P0 + val[e];
-            const float4 c = pool.col0[P];
-            stage[e] = c.x; stage[n_sort + e] = c.y; stage[2 * n_sort + e] = c.z;
-            if (pool.term_info[P] & 0x80u) val[e] |= 0x80000000u;
-        }
+    if (!is_sorted_lds(key, n_sort)) bitonic_sort_lds(key, n_sort); // sky-only pixels arrive sorted
+    const uint32_t cnt = count_valid_lds(key, n_sort, NOKEY);
+    for (uint32_t e = threadIdx.x; e < cnt; e += 64) {
+        const uint32_t lo = (uint32_t)key[e];
+        const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
+        stage[e] = c.x; stage[n_sort + e] = c.y; stage[2 * n_sort + e] = c.z;
+        flg[e] = (uint8_t)((lo >> 12) & 1u);
     }
     __syncthreads();
     if (threadIdx.x < 3) {
         const float* src = stage + threadIdx.x * n_sort;
         float c = 0.0f, b = 0.0f;
-        for (uint32_t e = 0; e < spp; e++) {
-            if (key[e] == NOKEY) break;
-            const float v = src[e];
-            if (val[e] & 0x80000000u) b += v; else c += v;
+        uint32_t e = 0;
+        for (; e + 8 <= cnt; e += 8) {
+            const float4 v0 = *(const float4*)(src + e), v1 = *(const float4*)(src + e + 4);
+            const uint2 f = *(const uint2*)(flg + e);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const bool bg = (((u < 4 ? f.x : f.y) >> (8 * (u & 3))) & 1u) != 0;
+                const float s = (bg ? b : c) + v[u];
+                b = bg ? s : b;
+                c = bg ? c : s;
+            }
+        }
+        for (; e < cnt; e++) {
+            if (flg[e]) b += src[e]; else c += src[e];
         }
         out_color[3 * fi + threadIdx.x] = c / n;
         out_background[3 * fi + threadIdx.x] = b / n;
@@ -1022,33 +1055,18 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
         uint32_t k = INVALID;
         if (i < spp) { uint32_t ob = __float_as_uint(pool.aov[P0 + i].w); if (ob != OBJ_NONE) k = (ob << 16) | i; }
         key32[i] = k;
-        val[i] = i;
     }
     __syncthreads();
-    if (key32[0] == INVALID && is_sorted_lds(key32, n_sort)) { // no depth-0 surface hit at all: INVALID everywhere
-        if (threadIdx.x == 3) out_alpha[fi] = 0.0f / n;
-        else if (threadIdx.x < 3) out_normal[3 * fi + threadIdx.x] = 0.0f / n;
-        return;
-    }
-    if (!is_sorted_lds(key32, n_sort)) bitonic_sort_lds(key32, val, n_sort);
-    for (uint32_t e = threadIdx.x; e < spp; e += 64) {
-        if (key32[e] != INVALID) {
-            const uint32_t P = P0 + val[e];
-            const float4 a = pool.aov[P];
-            stage[e] = a.x; stage[n_sort + e] = a.y; stage[2 * n_sort + e] = a.z;
-        }
+    if (!is_sorted_lds(key32, n_sort)) bitonic_sort_lds(key32, n_sort);
+    const uint32_t cnt0 = count_valid_lds(key32, n_sort, INVALID);
+    for (uint32_t e = threadIdx.x; e < cnt0; e += 64) {
+        const float4 a = pool.aov[P0 + (key32[e] & 0xFFFFu)];
+        stage[e] = a.x; stage[n_sort + e] = a.y; stage[2 * n_sort + e] = a.z;
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const float* src = stage + (threadIdx.x % 3) * n_sort;
-        float a = 0.0f;
-        for (uint32_t e = 0; e < spp; e++) {
-            if (key32[e] == INVALID) break;
-            a += threadIdx.x == 3 ? 1.0f : src[e];
-        }
-        if (threadIdx.x == 3) out_alpha[fi] = a / n;
-        else out_normal[3 * fi + threadIdx.x] = a / n;
-    }
+    // Alpha adds 1.0 per depth-0 surface sample: every partial sum is an integer < 2^24, so the serial sum is the count
+    if (threadIdx.x == 3) out_alpha[fi] = (float)cnt0 / n;
+    else if (threadIdx.x < 3) out_normal[3 * fi + threadIdx.x] = serial_sum(stage + threadIdx.x * n_sort, cnt0) / n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1158,7 +1176,7 @@ void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* al
 }
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {
-    uint32_t n_sort = 1;
+    uint32_t n_sort = 8;
     while (n_sort < spp) n_sort <<= 1;
     hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 28, s, sc, tiles, pool, out_color, out_alpha, out_background,
                        out_normal, n_sort);

@@ -136,7 +136,9 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
         d.sdf_radius = h.sdf_radius;
         {   // div_nr is exact while numerator, denominator and quotient stay far from the exponent limits
             const float lo = 8.6736174e-19f /* 2^-60 */, hi = 1.1529215e18f /* 2^60 */;
-            d.fast_div = (d.min_rad_sq >= lo && d.min_rad_sq <= hi && d.fixed_rad_sq >= lo && d.fixed_rad_sq <= hi) ? 1u : 0u;
+            // ... and the box fold's 2*clamp(p) is an exact product while |box_side| <= 2^60 (fma == mul, add)
+            const float bs = h.box_side < 0.0f ? -h.box_side : h.box_side;
+            d.fast_div = (d.min_rad_sq >= lo && d.min_rad_sq <= hi && d.fixed_rad_sq >= lo && d.fixed_rad_sq <= hi && bs <= hi) ? 1u : 0u;
         }
         if (h.kind == RAYN_HITABLE_TRACED_SDF) {
             s.n_sdf++;
