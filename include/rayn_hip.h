@@ -260,7 +260,11 @@ int64_t rayn_hip_get_trace(const rayn_ctx* ctx, uint32_t* out, uint64_t cap_reco
  * parity tests can compare single functions with the CPU oracle lane for lane:
  *   SDF::dist (src/sdf.rs:125-140), HitableStore::add_hits' closest hit (src/hitable.rs:177-198;
  *   out_obj 0xFFFFFFFF = none), HitableStore::test_occluded (src/hitable.rs:164-168), and the pinned
- *   elementary functions (op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b)). */
+ *   elementary functions (op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b)).
+ *   Ops 6.. check the kernels' exact replacements of IEEE '/' and sqrt against the hardware IEEE
+ *   result: 6 Newton-Raphson a/b, 7 IEEE a/b, 8 sqrt(a), 9/10/11 component x/y/z of v/|v| and
+ *   12 |v| (a holds n xyz triples), 13 exhaustive sqrt sweep (out[i] = mismatch count over the
+ *   65536 float bit patterns starting at bits(a[i])). */
 int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t hitable_index,
                             const float* pts_xyz, float* out, uint32_t n);
 int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth,

@@ -44,8 +44,42 @@ RD f3 operator/(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
 RD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 RD float dot(f3 a, f3 b) { return muladd(a.x, b.x, muladd(a.y, b.y, a.z * b.z)); }
 RD float mag_sq(f3 a) { return dot(a, a); }
-RD float mag(f3 a) { return __builtin_sqrtf(mag_sq(a)); }
+// Correctly rounded sqrt.  For x in [2^-60, 2^60) one v_rsq_f32 plus a residual correction gives the IEEE
+// result (verified EXHAUSTIVELY over that window on the device, tests/test_gpu_parity.py); every other input
+// (0, denormals, huge, inf, NaN, negative) takes hipcc's IEEE sequence.  16+6 VALU cycles instead of 46.
+RD float sqrt_rn(float x) {
+    if (__float_as_uint(x) - 0x21800000u < 0x3C000000u) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        const float g = x * y;
+        const float h = 0.5f * y;
+        const float d = __builtin_fmaf(-g, g, x);
+        return __builtin_fmaf(d, h, g);
+    }
+    return __builtin_sqrtf(x);
+}
+RD float mag(f3 a) { return sqrt_rn(mag_sq(a)); }
 RD f3 normalized(f3 a) { float r = 1.0f / mag(a); return f3{a.x * r, a.y * r, a.z * r}; }
+// a / m (three IEEE divisions in the reference) for m = mag(a): m >= |a_i| always (sqrt(fl(x*x + ..)) >= |x|),
+// so min|a_i| >= 2^-60 and m <= 2^60 put every operand and quotient inside the window where the Newton-Raphson
+// steps of an IEEE '/' need neither v_div_scale nor v_div_fixup (see div_nr); the reciprocal is refined once
+// and shared.  Anything else (zero components, NaN, extreme exponents) takes the IEEE divisions.
+RD f3 div_by_mag(f3 a, float m) {
+    const float mn = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    if (mn >= 8.6736174e-19f && m <= 1.1529215e18f) {
+        float r = __builtin_amdgcn_rcpf(m);
+        const float e0 = __builtin_fmaf(-m, r, 1.0f);
+        r = __builtin_fmaf(e0, r, r);
+        f3 q = f3{a.x * r, a.y * r, a.z * r};
+        q.x = __builtin_fmaf(__builtin_fmaf(-m, q.x, a.x), r, q.x);
+        q.y = __builtin_fmaf(__builtin_fmaf(-m, q.y, a.y), r, q.y);
+        q.z = __builtin_fmaf(__builtin_fmaf(-m, q.z, a.z), r, q.z);
+        q.x = __builtin_fmaf(__builtin_fmaf(-m, q.x, a.x), r, q.x);
+        q.y = __builtin_fmaf(__builtin_fmaf(-m, q.y, a.y), r, q.y);
+        q.z = __builtin_fmaf(__builtin_fmaf(-m, q.z, a.z), r, q.z);
+        return q;
+    }
+    return f3{a.x / m, a.y / m, a.z / m};
+}
 RD f3 cross(f3 a, f3 b) {
     return f3{muladd(a.y, b.z, -a.z * b.y), muladd(a.z, b.x, -a.x * b.z), muladd(a.x, b.y, -a.y * b.x)};
 }
@@ -87,13 +121,13 @@ RD f3 cosine_weighted_in_hemisphere(float u0, float u1) { // :99-103
     float x, y;
     concentric_circle_map(u0, u1, &x, &y);
     float m2 = muladd(x, x, y * y);
-    float z = __builtin_sqrtf(1.0f - fmins(m2, 1.0f));
+    float z = sqrt_rn(1.0f - fmins(m2, 1.0f));
     return f3{x, y, z};
 }
 RD f3 cosine_power_weighted(float u0, float u1, float power) { // :106-113
     float a = dm_powf(u0, 1.0f / (power + 1.0f));
     float a2 = a * a;
-    float b = __builtin_sqrtf(1.0f - a2);
+    float b = sqrt_rn(1.0f - a2);
     float s, c;
     dm_sincosf(2.0f * u1, &s, &c);
     return f3{b * c, b * s, a};
@@ -134,12 +168,12 @@ RD float mandelbulb_dist(f3 p, uint32_t iterations) {
     float dz = 1.0f;
     for (uint32_t i = 0; i < iterations; i++) {
         const float m2 = m * m, m4 = m2 * m2;
-        dz = 8.0f * __builtin_sqrtf(m4 * m2 * m) * dz + 1.0f;
+        dz = 8.0f * sqrt_rn(m4 * m2 * m) * dz + 1.0f;
         const float x = w.x, x2 = x * x, x4 = x2 * x2;
         const float y = w.y, y2 = y * y, y4 = y2 * y2;
         const float z = w.z, z2 = z * z, z4 = z2 * z2;
         const float k3 = x2 + z2;
-        const float k2 = 1.0f / __builtin_sqrtf(k3 * k3 * k3 * k3 * k3 * k3 * k3);
+        const float k2 = 1.0f / sqrt_rn(k3 * k3 * k3 * k3 * k3 * k3 * k3);
         const float k1 = x4 + y4 + z4 - 6.0f * y2 * z2 - 6.0f * x2 * y2 + 2.0f * z2 * x2;
         const float k4 = x2 - y2 + z2;
         w.x = p.x + 64.0f * x * y * z * (x2 - z2) * k4 * (x4 - 6.0f * x2 * z2 + z4) * k1 * k2;
@@ -148,7 +182,7 @@ RD float mandelbulb_dist(f3 p, uint32_t iterations) {
         m = w.x * w.x + w.y * w.y + w.z * w.z;
         if (m > 256.0f) break;
     }
-    return 0.25f * dm_logf(m) * __builtin_sqrtf(m) / dz;
+    return 0.25f * dm_logf(m) * sqrt_rn(m) / dz;
 }
 
 // Correctly rounded n/d for finite normal n, d whose quotient is a normal number: the same Newton-Raphson
@@ -247,7 +281,7 @@ template <bool COUNT>
 RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, uint32_t& evals) {
     f3 dir = end - start;
     float max_dist = mag(dir);
-    dir = dir / max_dist;
+    dir = div_by_mag(dir, max_dist);
     float dist0 = sdf_dist<COUNT>(h, start, evals);
     const bool nan = dist0 != dist0;
     if (sc.max_vis_marches == 0) return ((dist0 < 0.0001f) && !((dist0 > max_dist) || nan)) ? 0.0f : 1.0f;
@@ -285,7 +319,7 @@ RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max, float t0) {
     float descrim = b * b - c;
     bool desc_pos = descrim > 0.0f;
     if (!desc_pos) return 3.40282347e+38f; // both roots are invalid whatever sqrt returns: skip it (exact)
-    float desc_sqrt = __builtin_sqrtf(descrim);
+    float desc_sqrt = sqrt_rn(descrim);
     float t1 = -b - desc_sqrt;
     bool t1_valid = (t1 > 0.0001f) && (t1 <= t_max) && desc_pos;
     float t2 = -b + desc_sqrt;
@@ -294,22 +328,34 @@ RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max, float t0) {
     float t = take_t1 ? t1 : t2;
     return (t1_valid || t2_valid) ? t : 3.40282347e+38f;
 }
-RD float sphere_occluded(const DHitable& h, f3 start, f3 end, float t0) {
-    f3 dir = end - start;
-    float dist = mag(dir);
-    dir = dir / dist;
+// Sphere::occluded (src/sphere.rs:49-71) with the segment direction and length computed once by the caller
+// (they do not depend on the sphere).  Two exact early-outs, both "this sphere cannot occlude":
+//  * b >= 0 (sphere centre behind the start): t1 = -b - sqrt(..) is a sum of two non-positive numbers, so
+//    min(t1, t2) <= 0 and the reference's 'min > 0.001' test fails;
+//  * c < -1e-30 (start inside the sphere, e.g. the sky dome): descrim = fl(fl(b*b) - c) >= fl(b*b), sqrt is
+//    monotonic and sqrt(fl(b*b)) == |b| (or descrim >= 1e-30 > b*b when b*b underflows), so again t1 <= 0.
+// NaN operands fail both tests and take the literal path.
+RD float sphere_occluded_dir(const DHitable& h, f3 start, f3 dir, float dist, float t0) {
     f3 oc = start - sphere_center(h, t0);
     float b = dot(oc, dir);
+    if (b >= 0.0f) return 1.0f;
     float c = mag_sq(oc) - h.radius_sq;
+    if (c < -1e-30f) return 1.0f;
     float descrim = b * b - c;
     bool desc_pos = descrim > 0.0f;
     if (!desc_pos) return 1.0f; // 'valid' needs desc_pos: the segment cannot be occluded by this sphere (exact)
-    float desc_sqrt = __builtin_sqrtf(descrim);
+    float desc_sqrt = sqrt_rn(descrim);
     float t1 = -b - desc_sqrt;
     float t2 = -b + desc_sqrt;
     float mn = fmins(t1, t2);
     bool valid = (mn > 0.001f) && (t1 <= dist) && desc_pos;
     return valid ? 0.0f : 1.0f;
+}
+RD float sphere_occluded(const DHitable& h, f3 start, f3 end, float t0) {
+    f3 dir = end - start;
+    float dist = mag(dir);
+    dir = div_by_mag(dir, dist);
+    return sphere_occluded_dir(h, start, dir, dist, t0);
 }
 
 // HitableStore::add_hits fold, src/hitable.rs:177-198: closest-so-far is the next t_max.
@@ -340,18 +386,18 @@ RD float test_occluded(const DScene& sc, f3 start, f3 end, float t0, uint32_t& e
 RD void light_sample(const DLight& L, float u0, float u1, f3 p, f3* out_point, float* out_pdf) {
     f3 dir_to_light = L.pos - p;
     float dist_sq = mag_sq(dir_to_light);
-    float dist = __builtin_sqrtf(dist_sq);
-    dir_to_light = dir_to_light / dist;
+    float dist = sqrt_rn(dist_sq);
+    dir_to_light = div_by_mag(dir_to_light, dist);
     Basis basis = orthonormal_basis(-dir_to_light);
     float r2 = L.rad * L.rad;
     float sin_theta_max_2 = r2 / dist_sq;
-    float cos_theta_max = __builtin_sqrtf(fmaxs(0.0f, 1.0f - sin_theta_max_2));
+    float cos_theta_max = sqrt_rn(fmaxs(0.0f, 1.0f - sin_theta_max_2));
     float cos_theta = (1.0f - u0) + u0 * cos_theta_max;
-    float sin_theta = __builtin_sqrtf(fmaxs(0.0f, 1.0f - cos_theta * cos_theta));
+    float sin_theta = sqrt_rn(fmaxs(0.0f, 1.0f - cos_theta * cos_theta));
     float phi = u1 * TWO_PI_F;
-    float ds = dist * cos_theta - __builtin_sqrtf(fmaxs(0.0f, r2 - dist_sq * sin_theta * sin_theta));
+    float ds = dist * cos_theta - sqrt_rn(fmaxs(0.0f, r2 - dist_sq * sin_theta * sin_theta));
     float cos_alpha = (dist_sq + r2 - ds * ds) / (2.0f * dist * L.rad);
-    float sin_alpha = __builtin_sqrtf(fmaxs(0.0f, 1.0f - cos_alpha * cos_alpha));
+    float sin_alpha = sqrt_rn(fmaxs(0.0f, 1.0f - cos_alpha * cos_alpha));
     float sin_phi, cos_phi;
     dm_sincosf(phi, &sin_phi, &cos_phi);
     f3 offset = basis.c0 * sin_alpha * cos_phi + basis.c1 * sin_alpha * sin_phi + basis.c2 * cos_alpha;

@@ -561,8 +561,11 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
     };
     // analytic spheres of test_occluded (every factor is exactly 0 or 1 -> order independent)
     auto spheres_visible = [&](f3 a, f3 b) {
+        f3 dir = b - a;
+        const float dist = mag(dir);
+        dir = div_by_mag(dir, dist);
         for (uint32_t k = 0; k < sc.n_hitables; k++)
-            if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], a, b, t0) == 0.0f) return false;
+            if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded_dir(sc.h[k], a, dir, dist, t0) == 0.0f) return false;
         return true;
     };
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0}, rad = f3{0, 0, 0}, thr = f3{0, 0, 0}, point = f3{0, 0, 0}, normal = f3{0, 0, 1};
@@ -609,7 +612,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ 
                 light_sample(L, u0, u1, point, &end_point, &pdf);
                 f3 wi = end_point - point;
                 float dist = mag(wi);
-                wi = wi / dist;
+                wi = div_by_mag(wi, dist);
                 f3 occlude_point = point + normal * signum(dot(normal, wi)) * offset_by;
                 const float ndw = dot(normal, wi);
                 const float cosw = fmaxs(ndw, 0.0f);
@@ -778,7 +781,7 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
                     const f3 e = f3{ja.w, jb.x, jb.y};
                     dir = e - start;
                     max_dist = mag(dir);
-                    dir = dir / max_dist;
+                    dir = div_by_mag(dir, max_dist);
                     k = 0; has = true;
                     next_sdf();
                 }
@@ -853,7 +856,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                     const f3 e = f3{ja.w, jb.x, jb.y};
                     n_dir = e - n_start;
                     n_max = mag(n_dir);
-                    n_dir = n_dir / n_max;
+                    n_dir = div_by_mag(n_dir, n_max);
                     n_has = true;
                 }
                 cur += min((uint32_t)__popcll(need), avail);
@@ -1107,6 +1110,26 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
     case 4: r = dm_atan2f(a[i], b[i]); break;
     case 5: r = dm_powf(a[i], b[i]); break;
     case 6: r = div_nr(a[i], b[i]); break;
+    case 7: r = a[i] / b[i]; break;
+    case 8: r = sqrt_rn(a[i]); break;
+    case 9: case 10: case 11: case 12: { // a holds n xyz triples
+        const f3 v = f3{a[3 * i], a[3 * i + 1], a[3 * i + 2]};
+        const float m = mag(v);
+        const f3 q = div_by_mag(v, m);
+        r = op == 9 ? q.x : (op == 10 ? q.y : (op == 11 ? q.z : m));
+        break;
+    }
+    case 13: { // exhaustive sweep: sqrt_rn against the IEEE sqrt over the 65536 bit patterns from bits(a[i]); returns the mismatch count
+        const uint32_t base = __float_as_uint(a[i]);
+        uint32_t bad = 0;
+        for (uint32_t j = 0; j < 65536u; j++) {
+            const float x = __uint_as_float(base + j);
+            const float s0 = sqrt_rn(x), s1 = __builtin_sqrtf(x);
+            bad += (__float_as_uint(s0) != __float_as_uint(s1)) && !(s0 != s0 && s1 != s1);
+        }
+        r = (float)bad;
+        break;
+    }
     default: r = a[i] / b[i]; break;
     }
     out[i] = r;

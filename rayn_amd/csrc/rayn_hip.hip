@@ -723,8 +723,9 @@ int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const flo
     const KernelSet K = kernel_set(ctx->fma_policy);
     HIPCHK(hipSetDevice(ctx->device));
     float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc((void**)&d_a, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
-    HIPCHK(hipMemcpy(d_a, a, (size_t)n * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    const size_t na = (op >= 9 && op <= 12) ? (size_t)n * 3 : (size_t)n; // ops 9..12 read xyz triples from a
+    HIPCHK(hipMalloc((void**)&d_a, na * 4)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_a, a, na * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, b, (size_t)n * 4, hipMemcpyHostToDevice));
     K.probe_detmath(ctx->stream, op, d_a, d_b, d_out, n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -48,6 +48,52 @@ def test_fast_division_is_ieee(gpu_ctx):
     assert np.array_equal(out.view(np.uint32), (num / den).view(np.uint32))
 
 
+def test_fast_sqrt_is_ieee_exhaustive(gpu_ctx):
+    """sqrt_rn (rsq + one residual correction inside [2^-60, 2^60), hipcc's IEEE sqrt elsewhere) == IEEE sqrt for EVERY
+    non-negative float bit pattern, plus negative / NaN samples."""
+    import ctypes as C
+    from rayn_amd._lib import lib
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    bases = (np.arange(0, 0x7F80_0000 + 65536, 65536, dtype=np.uint64)).astype(np.uint32)  # covers 0 .. +inf and the first NaNs
+    out = np.zeros(bases.size, np.float32)
+    dummy = np.zeros(bases.size, np.float32)
+    assert lib().rayn_hip_probe_detmath(gpu_ctx.h, 13, fp(bases.view(np.float32)), fp(dummy), fp(out), bases.size) == 0
+    assert out.sum() == 0, f"{int(out.sum())} mismatching inputs, first block base 0x{int(bases[np.argmax(out > 0)]):08x}"
+    x = np.concatenate([_rand(100000, -1e6, 1e6, 3), np.array([-0.0, np.nan, -np.inf, np.inf, 0.0], np.float32)])
+    got = np.zeros_like(x)
+    assert lib().rayn_hip_probe_detmath(gpu_ctx.h, 8, fp(x), fp(x), fp(got), x.size) == 0
+    with np.errstate(invalid="ignore"):
+        assert bits_equal(got, np.sqrt(x))
+
+
+def test_fast_normalise_is_ieee(gpu_ctx):
+    """v / |v| through div_by_mag (shared refined reciprocal inside the exponent window, IEEE divisions outside) ==
+    three IEEE divisions, for ordinary vectors, vectors with zero / tiny / huge components and extreme ratios."""
+    import ctypes as C
+    from rayn_amd._lib import lib
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    rng = np.random.default_rng(11)
+    n = 1_000_000
+    v = rng.uniform(-1, 1, (n, 3))
+    v *= np.exp2(rng.integers(-70, 71, (n, 1)).astype(np.float64))          # whole-vector scale across and beyond the window
+    v[: n // 4] *= np.exp2(rng.integers(-40, 1, (n // 4, 3)).astype(np.float64))  # very uneven components
+    v = v.astype(np.float32)
+    v[:1000, 0] = 0.0; v[1000:2000, 1] = -0.0; v[2000:2100] = 0.0; v[2100:2200, 2] = np.float32(1e-42)
+    v[2200:2300, 0] = np.inf; v[2300:2400, 1] = np.nan
+    dummy = np.zeros(n, np.float32)
+    res = []
+    for op in (9, 10, 11, 12):
+        out = np.zeros(n, np.float32)
+        assert lib().rayn_hip_probe_detmath(gpu_ctx.h, op, fp(v), fp(dummy), fp(out), n) == 0
+        res.append(out)
+    with np.errstate(all="ignore"):
+        x, y, z = v[:, 0], v[:, 1], v[:, 2]
+        m = np.sqrt(x * x + (y * y + z * z))  # dot(): muladd(x, x, muladd(y, y, z * z)), unfused
+        assert bits_equal(res[3], m)
+        for c in range(3):
+            assert bits_equal(res[c], v[:, c] / m), c
+
+
 def _probe_setup(gpu_ctx, name):
     wd, p = case(name, 64, 64, 1, 3)
     gpu_ctx.upload_world(wd)
