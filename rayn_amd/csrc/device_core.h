@@ -185,6 +185,13 @@ RD float mandelbulb_dist(f3 p, uint32_t iterations) {
     return 0.25f * dm_logf(m) * sqrt_rn(m) / dz;
 }
 
+// max(a, b) for non-NaN operands as a single instruction
+RD float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Correctly rounded n/d for finite normal n, d whose quotient is a normal number: the same Newton-Raphson
 // + residual-correction steps hipcc emits for an IEEE '/', minus v_div_scale / v_div_fixup (which only act
 // on extreme exponents and specials).  22 VALU cycles instead of 36.  The host enables it per object only
@@ -208,25 +215,29 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
         const f3 offset = p;
         float dr = 1.0f;
         const float l = h.box_l, nl = -h.box_l, s = h.scale;
-        const float mrs = h.min_rad_sq, frs = h.fixed_rad_sq, inf = __builtin_inff();
+        const float mrs = h.min_rad_sq, frs = h.fixed_rad_sq;
         // if min_rad_sq > fixed_rad_sq the quotient is < 1 for every r2: never enter the block
         const float frs_eff = mrs <= frs ? frs : -1.0f;
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
-#define RAYN_FOLD_BODY(DIV, BOX)                                                                  \
-        for (uint32_t i = 0; i < h.iterations; i++) {                                         \
+#define RAYN_FOLD_ITER(DIV, BOX)                                                                  \
+        {                                                                                     \
             /* box_fold: clamped(-l, l).mul_add(2, -p) */                                     \
             p.x = BOX(__builtin_amdgcn_fmed3f(p.x, nl, l), p.x);                              \
             p.y = BOX(__builtin_amdgcn_fmed3f(p.y, nl, l), p.y);                              \
             p.z = BOX(__builtin_amdgcn_fmed3f(p.z, nl, l), p.z);                              \
             /* sphere_fold: mul = max(1, R2 / max(r2min, r2)).  For r2 >= R2 (and for NaN) the quotient  \
-               is <= 1, mul is exactly 1 and the two multiplies are identities, so the whole block is     \
-               skipped - the compiler branches around it when no lane of the wave needs it, which is the  \
-               common case once an orbit escapes.  For r2 < R2 the quotient is >= 1: max(1, q) == q. */   \
+               is <= 1, mul is exactly 1 and the multiplies are identities, so the block only matters for  \
+               lanes with r2 < R2, where the quotient is >= 1: max(1, q) == q.  The test is made         \
+               WAVE-UNIFORM (ballot -> scalar branch, block out of line): a per-lane 'if' costs a         \
+               v_cmp + s_and_saveexec + taken s_cbranch_execz per iteration, measured at 15 of the loop's \
+               66 cycles (tools/ubench/fold_rate.hip); inside, lanes that do not fold multiply by 1. */   \
             const float r2 = mag_sq(p);                                                       \
-            if (r2 < frs_eff) {                                                               \
-                /* med3(r2, mrs, +inf) == max(mrs, r2) without the canonicalising v_max of fmaxf */ \
-                const float m = DIV(frs, __builtin_amdgcn_fmed3f(r2, mrs, inf));              \
+            const bool fold = r2 < frs_eff;                                                   \
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(fold) != 0, 0)) {                \
+                /* r2 is not NaN on a folding lane: ONE raw v_max_f32 (fmaxf / med3 lower to three, two of  \
+                   them canonicalising no-ops) */                                             \
+                const float m = fold ? DIV(frs, vmax_raw(r2, mrs)) : 1.0f;                    \
                 p.x *= m; p.y *= m; p.z *= m;                                                 \
                 dr *= m;                                                                      \
             }                                                                                 \
@@ -239,8 +250,19 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
 #define RAYN_BOX_REF(c, q) muladd(c, 2.0f, -(q))
         // |c| <= |l| <= 2^60: the product 2c is exact, so ONE rounding (fma) == the reference's two (mul, add)
 #define RAYN_BOX_FMA(c, q) __builtin_fmaf(c, 2.0f, -(q))
-        if (h.fast_div) { RAYN_FOLD_BODY(div_nr, RAYN_BOX_FMA) } else { RAYN_FOLD_BODY(RAYN_DIV_IEEE, RAYN_BOX_REF) }
-#undef RAYN_FOLD_BODY
+        if (h.fast_div) {
+            // unrolled by 4 by hand (the ballot is a convergent operation, which stops the loop unroller): the taken
+            // back-edge of the rolled loop costs about as much as four VALU operations per iteration
+            uint32_t i = 0;
+            for (; i + 4 <= h.iterations; i += 4) {
+                RAYN_FOLD_ITER(div_nr, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_nr, RAYN_BOX_FMA)
+                RAYN_FOLD_ITER(div_nr, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_nr, RAYN_BOX_FMA)
+            }
+            for (; i < h.iterations; i++) RAYN_FOLD_ITER(div_nr, RAYN_BOX_FMA)
+        } else {
+            for (uint32_t i = 0; i < h.iterations; i++) RAYN_FOLD_ITER(RAYN_DIV_IEEE, RAYN_BOX_REF)
+        }
+#undef RAYN_FOLD_ITER
 #undef RAYN_DIV_IEEE
 #undef RAYN_BOX_REF
 #undef RAYN_BOX_FMA
