@@ -95,6 +95,7 @@ struct Tables {
     void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n); \
     void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n); \
     void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const float* b, float* out, uint32_t n); \
+    void launch_verify_short_div(hipStream_t s, float n, uint32_t lo_bits, uint32_t count, uint32_t* bad); \
     }
 RAYN_DECLARE_LAUNCHERS(rayn_p0)
 RAYN_DECLARE_LAUNCHERS(rayn_p1)

@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
     bool exhausted = false, endgame = false;
+    uint32_t trips64 = 0; (void)trips64;
     // current ray
     bool c_has = false, first = false, nan = false;
     uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0, evals = 0;
@@ -286,6 +287,9 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
             if (exhausted) break;
             continue;
         }
+#ifdef RAYN_COUNT_TRIPS
+        if (COUNT && lane == 0) trips64 += 64;
+#endif
         if (c_has) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
             const f3 p = first ? o : muladd3(d, t, o);
             const float dist = sdf_dist<COUNT>(h, p, evals);
@@ -310,6 +314,9 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
             }
         }
     }
+#ifdef RAYN_COUNT_TRIPS
+    evals = trips64;
+#endif
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
@@ -826,6 +833,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
     bool exhausted = false, endgame = false;
+    uint32_t trips64 = 0; (void)trips64;
     bool c_has = false, first = false, nan = false, n_has = false;
     uint32_t ref = 0, n_ref = 0, m = 0, evals = 0;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
@@ -871,6 +879,9 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             if (exhausted) break;
             continue;
         }
+#ifdef RAYN_COUNT_TRIPS
+        if (COUNT && lane == 0) trips64 += 64;
+#endif
         if (c_has) { // TracedSDF::occluded, src/sdf.rs:25-57
             const f3 p = first ? start : muladd3(dir, t, start);
             const float dist = sdf_dist<COUNT>(h, p, evals);
@@ -889,6 +900,9 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             if (res >= 0) { nee.vis[ref] = (uint8_t)res; c_has = false; }
         }
     }
+#ifdef RAYN_COUNT_TRIPS
+    evals = trips64;
+#endif
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
@@ -1130,9 +1144,42 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
         r = (float)bad;
         break;
     }
+    case 14: case 15: { // experiment: short division variants b[i] / d over 65536 bit patterns of d from bits(a[i]); returns mismatch count
+        const uint32_t base = __float_as_uint(a[i]);
+        const float n = b[i];
+        uint32_t bad = 0;
+        for (uint32_t j = 0; j < 65536u; j++) {
+            const float d = __uint_as_float(base + j);
+            float q;
+            if (op == 14) { // rcp, mul, one residual correction
+                const float rc = __builtin_amdgcn_rcpf(d);
+                q = n * rc;
+                q = __builtin_fmaf(__builtin_fmaf(-d, q, n), rc, q);
+            } else { // rcp refined once, mul, one residual correction
+                float rc = __builtin_amdgcn_rcpf(d);
+                rc = __builtin_fmaf(__builtin_fmaf(-d, rc, 1.0f), rc, rc);
+                q = n * rc;
+                q = __builtin_fmaf(__builtin_fmaf(-d, q, n), rc, q);
+            }
+            bad += __float_as_uint(q) != __float_as_uint(n / d);
+        }
+        r = (float)bad;
+        break;
+    }
     default: r = a[i] / b[i]; break;
     }
     out[i] = r;
+}
+
+// Scene-upload check behind DHitable::fast_div == 2: div_short(n, d) against the IEEE quotient for every float d with
+// bit pattern in [lo_bits, lo_bits + count).
+__global__ void __launch_bounds__(256) k_verify_short_div(float n, uint32_t lo_bits, uint32_t count, uint32_t* __restrict__ bad) {
+    uint32_t local = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
+        const float d = __uint_as_float(lo_bits + (uint32_t)j);
+        local += __float_as_uint(div_short(n, d)) != __float_as_uint(n / d);
+    }
+    if (local) atomicAdd(bad, local);
 }
 
 // ---- launch wrappers (declared in kernels.h) -----------------------------------------------------
@@ -1212,6 +1259,9 @@ void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const
 }
 void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n) {
     hipLaunchKernelGGL(k_probe_occluded, grid_for(n, 256), dim3(256), 0, s, sc, a, b, out, n);
+}
+void launch_verify_short_div(hipStream_t s, float n, uint32_t lo_bits, uint32_t count, uint32_t* bad) {
+    hipLaunchKernelGGL(k_verify_short_div, dim3(4096), dim3(256), 0, s, n, lo_bits, count, bad);
 }
 void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const float* b, float* out, uint32_t n) {
     hipLaunchKernelGGL(k_probe_detmath, grid_for(n, 256), dim3(256), 0, s, op, a, b, out, n);

@@ -81,6 +81,9 @@ struct rayn_ctx {
     int trace_tile = -1;             // diagnostics: dump the packet order of this tile (rayn_hip_set_trace_tile)
     std::vector<uint32_t> trace;     // records of 6 u32: depth, object, tile x, tile y, sample, valid
     int fma_policy = 0; // 0: mul_add unfused (reference default build), 1: fused
+    // (bits(min_radius^2), bits(fixed_radius^2)) pairs whose sphere-fold division was checked exhaustively on the device,
+    // with the verdict (true = the 4-instruction division is exact for every reachable denominator)
+    std::vector<std::pair<std::pair<uint32_t, uint32_t>, bool>> short_div_verdicts;
 };
 
 namespace {
@@ -114,6 +117,29 @@ std::vector<TileRect> build_tiles(uint32_t W, uint32_t H, uint32_t tw, uint32_t 
 
 f3 to3(rayn_vec3 v) { return f3{v.x, v.y, v.z}; }
 
+uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+// DHitable::fast_div == 2 gate: run k_verify_short_div over every denominator max(r2, mrs) with r2 < frs can take, i.e.
+// all floats in [mrs, frs) (positive floats are ordered like their bit patterns); cached per (mrs, frs).
+bool short_div_is_exact(rayn_ctx* ctx, float mrs, float frs) {
+    if (!(mrs > 0.0f) || !(mrs < frs)) return false;
+    const std::pair<uint32_t, uint32_t> key(f32_bits(mrs), f32_bits(frs));
+    for (const auto& e : ctx->short_div_verdicts) if (e.first == key) return e.second;
+    bool ok = false;
+    uint32_t* d_bad = nullptr;
+    uint32_t bad = 1;
+    if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc((void**)&d_bad, 4) == hipSuccess) {
+        if (hipMemsetAsync(d_bad, 0, 4, ctx->stream) == hipSuccess) {
+            rayn_p0::launch_verify_short_div(ctx->stream, frs, key.first, key.second - key.first, d_bad);
+            if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess)
+                ok = bad == 0;
+        }
+        hipFree(d_bad);
+    }
+    ctx->short_div_verdicts.emplace_back(key, ok);
+    return ok;
+}
+
 int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params& p, DScene* out) {
     DScene& s = *out;
     memset(&s, 0, sizeof s);
@@ -139,6 +165,9 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
             // ... and the box fold's 2*clamp(p) is an exact product while |box_side| <= 2^60 (fma == mul, add)
             const float bs = h.box_side < 0.0f ? -h.box_side : h.box_side;
             d.fast_div = (d.min_rad_sq >= lo && d.min_rad_sq <= hi && d.fixed_rad_sq >= lo && d.fixed_rad_sq <= hi && bs <= hi) ? 1u : 0u;
+            // ... and the 4-instruction division when the device has verified it for every reachable denominator
+            if (d.fast_div && h.kind == RAYN_HITABLE_TRACED_SDF && h.sdf_kind == RAYN_SDF_MANDELBOX && short_div_is_exact(ctx, d.min_rad_sq, d.fixed_rad_sq))
+                d.fast_div = 2u;
         }
         if (h.kind == RAYN_HITABLE_TRACED_SDF) {
             s.n_sdf++;
