@@ -35,6 +35,9 @@ WORKLOADS = {
     "c2": ("s1", 1920, 1080, 64, 8, "1920x1080, 256 spp, 8 bounces, MandelBox SDF (reference fractal), volumes off [BASELINE configs[1]]"),
     "c3": ("s2", 1920, 1080, 256, 8, "1920x1080, 1024 spp, 8 bounces, MandelBox SDF + homogeneous volume [BASELINE configs[2]]"),
     "c1": ("s0", 256, 256, 4, 4, "256x256, 16 spp, 4 bounces, single-sphere SDF [BASELINE configs[0]]"),
+    "c4": ("s1", 3840, 2160, 256, 12, "3840x2160, 1024 spp, 12 bounces, MandelBox SDF, volumes off [BASELINE configs[3], an 8-GPU config: 8.49 G paths]"),
+    "c5": ("s3", 7680, 4320, 1024, 16, "7680x4320, 4096 spp, 16 bounces, MandelBox SDF, moving camera with time-sampled motion blur "
+           "[BASELINE configs[4], an 8-GPU config: 135.9 G paths; the reference's SDF itself is not time-dependent]"),
     "bulb": ("bulb", 1920, 1080, 64, 8, "1920x1080, 256 spp, 8 bounces, power-8 Mandelbulb SDF (EXTENSION: the fractal BASELINE.json names; not in the reference), volumes off"),
     "mid": ("s1", 960, 540, 16, 8, "960x540, 64 spp, 8 bounces, MandelBox (profiling-sized)"),
     "small": ("s1", 480, 270, 4, 3, "480x270, 16 spp, 3 bounces, MandelBox (quick check)"),
@@ -77,7 +80,7 @@ def main():
 
     scene, W, H, samples, bounces, desc = WORKLOADS[args.workload]
     spp = 4 * samples
-    cam, wld = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "bulb": S.setup_bulb}[scene]((W, H))
+    cam, wld = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb}[scene]((W, H))
     wd = wld.to_desc(cam)
     p = rayn_amd.frame_params(W, H, samples, bounces, tile_first=rank, tile_step=world)
     tabs = rayn_amd.build_tables(spp, bounces, p.volume_marches, p.frame, W, H)

@@ -220,9 +220,16 @@ int rayn_build_rd_tables(uint32_t spp, uint32_t sets_1d, uint32_t sets_2d, uint6
                          float* samples_1d, float* samples_2d);
 /* SmallRng::seed_from_u64(x + y*width).gen::<f32>() for every pixel, src/film.rs:460-461. */
 int rayn_build_scramble(uint32_t width, uint32_t height, float* scramble);
-/* FilterImportanceSampler::new(&BlackmanHarrisFilter::new(radius)), src/filter.rs:12-49,187-220.
- * filter_kind: 0 BlackmanHarris, 1 Box. */
+/* FilterImportanceSampler::new(&F::new(..)), src/filter.rs:187-220, for the reference's four Filter
+ * implementations (src/filter.rs:12-49 BlackmanHarris, :51-108 MitchellNetravali(radius, b, c),
+ * :110-140 Box, :142-185 LanczosSinc(radius, tau)).  rayn_build_fis_table takes the two
+ * parameter-free kinds; _ex takes all four (param0/param1 = b/c for Mitchell, tau/unused for
+ * Lanczos).  The sampler assumes a filter without negative lobes (src/filter.rs:194-195); like
+ * the reference the builder does not check that. */
+enum { RAYN_FILTER_BLACKMAN_HARRIS = 0, RAYN_FILTER_BOX = 1, RAYN_FILTER_MITCHELL = 2, RAYN_FILTER_LANCZOS = 3 };
 int rayn_build_fis_table(uint32_t filter_kind, float radius, float* table512);
+int rayn_build_fis_table_ex(uint32_t filter_kind, float radius, float param0, float param1,
+                            float* table512);
 /* number of tiles render_frame_into builds, incl. its under-coverage quirk (src/film.rs:399-404). */
 uint32_t rayn_tile_count(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h);
 

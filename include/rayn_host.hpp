@@ -17,7 +17,7 @@
 //   Pinhole/ThinLens/OrthographicCamera::new, CameraStore   src/camera.rs
 //   VolumeParams, World              src/volume.rs, src/world.rs
 //   PathTracingIntegrator            src/integrator.rs:32-45
-//   BlackmanHarrisFilter / BoxFilter src/filter.rs:12-49,110-140
+//   BlackmanHarrisFilter / BoxFilter / MitchellNetravaliFilter / LanczosSincFilter src/filter.rs:12-185
 //   Film::new / render_frame_into    src/film.rs:184-203, 382-395
 //   setup::setup()                   src/setup.rs:46-170
 #pragma once
@@ -203,6 +203,24 @@ struct BlackmanHarrisFilter { float radius_ = 1.5f; static BlackmanHarrisFilter 
                               float radius() const { return radius_; } static constexpr uint32_t kind = 0; };
 struct BoxFilter { float radius_ = 0.5f; static BoxFilter new_(float r) { return BoxFilter{r}; }
                    float radius() const { return radius_; } static constexpr uint32_t kind = 1; };
+struct MitchellNetravaliFilter { // src/filter.rs:51-108
+    float radius_ = 2.0f, b = 1.0f / 3.0f, c = 1.0f / 3.0f;
+    static MitchellNetravaliFilter new_(float r, float b, float c) { return MitchellNetravaliFilter{r, b, c}; }
+    float radius() const { return radius_; } float param0() const { return b; } float param1() const { return c; }
+    static constexpr uint32_t kind = 2;
+};
+struct LanczosSincFilter { // src/filter.rs:142-185
+    float radius_ = 3.0f, tau = 3.0f;
+    static LanczosSincFilter new_(float r, float tau) { return LanczosSincFilter{r, tau}; }
+    float radius() const { return radius_; } float param0() const { return tau; } float param1() const { return 0.0f; }
+    static constexpr uint32_t kind = 3;
+};
+namespace detail { // parameter-free filters have no param0()/param1()
+template <class F> auto filter_p0(const F& f, int) -> decltype(f.param0()) { return f.param0(); }
+template <class F> float filter_p0(const F&, long) { return 0.0f; }
+template <class F> auto filter_p1(const F& f, int) -> decltype(f.param1()) { return f.param1(); }
+template <class F> float filter_p1(const F&, long) { return 0.0f; }
+}
 
 // constants the tile closure reads (src/setup.rs:16-44, src/sdf.rs:9-10)
 struct RenderConstants { uint32_t max_marches = 256, max_vis_marches = 100; float sdf_detail_scale = 0.5f, world_radius = 100.0f; };
@@ -245,7 +263,7 @@ class Film {
         std::vector<float> s1((size_t)spp * sets_1d), s2((size_t)spp * 2 * sets_2d), scr((size_t)res_.w * res_.h), fis(RAYN_FIS_TABLE_SIZE);
         check(rayn_build_rd_tables(spp, sets_1d, sets_2d, frame, s1.data(), s2.data()));   // Samples::new_rd, src/film.rs:434
         check(rayn_build_scramble(res_.w, res_.h, scr.data()));                              // src/film.rs:460-461
-        check(rayn_build_fis_table(F::kind, filter.radius(), fis.data()));                   // src/film.rs:429
+        check(rayn_build_fis_table_ex(F::kind, filter.radius(), detail::filter_p0(filter, 0), detail::filter_p1(filter, 0), fis.data()));                   // src/film.rs:429
         check(rayn_hip_render_frame(ctx_, &p, s1.data(), s2.data(), scr.data(), fis.data(), color.data(), alpha.data(), background.data(),
                                     world_normal.data()));
         progressive_epoch++;

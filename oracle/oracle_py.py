@@ -47,6 +47,7 @@ def lib(fma=False):
         L.oracle_build_rd_tables.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp, fp]
         L.oracle_build_scramble.argtypes = [C.c_uint32, C.c_uint32, fp]
         L.oracle_build_fis_table.argtypes = [C.c_uint32, C.c_float, fp]
+        L.oracle_build_fis_table_ex.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_float, fp]
         _libs[name] = L
     return _libs[name]
 
@@ -59,7 +60,7 @@ def _up(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
-def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter_kind=0, filter_radius=1.5, fma=False):
+def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter_kind=0, filter_radius=1.5, fma=False, filter_params=(0.0, 0.0)):
     """Samples::new_rd + per-pixel scramble + FilterImportanceSampler::new, oracle versions."""
     L = lib(fma)
     n1 = L.oracle_sets_1d(max_bounces, volume_marches)
@@ -70,7 +71,7 @@ def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter_
     scr = np.zeros(width * height, np.float32)
     L.oracle_build_scramble(width, height, _fp(scr))
     fis = np.zeros(512, np.float32)
-    L.oracle_build_fis_table(filter_kind, filter_radius, _fp(fis))
+    L.oracle_build_fis_table_ex(filter_kind, filter_radius, filter_params[0], filter_params[1], _fp(fis))
     return s1, s2, scr, fis
 
 

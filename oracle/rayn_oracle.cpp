@@ -1019,24 +1019,55 @@ float pcg_scramble(uint64_t state) {
     uint32_t v = (uint32_t)r; /* next_u32 */
     return (float)(v >> 8) * (1.0f / 16777216.0f);
 }
-/* BlackmanHarrisFilter::evaluate, src/filter.rs:37-49; BoxFilter::evaluate :131-139 */
-float filter_eval(uint32_t kind, float radius, float p) {
-    if (kind == 1) return __builtin_fabsf(p) > radius ? 0.0f : 1.0f;
-    const float A0 = 0.35875f, A1 = 0.48829f, A2 = 0.14128f, A3 = 0.01168f;
-    const float TWOPI = PI_F * 2.0f, FOURPI = PI_F * 4.0f, SIXPI = PI_F * 6.0f;
-    if (__builtin_fabsf(p) > radius) return 0.0f;
-    float x = __builtin_fabsf(p / radius) * 0.5f + 0.5f;
-    return A0 - A1 * dm_cosf(TWOPI * x) + A2 * dm_cosf(FOURPI * x) + A3 * dm_cosf(SIXPI * x);
+/* Filter::evaluate.  kind 0 BlackmanHarrisFilter src/filter.rs:37-49; 1 BoxFilter :127-140;
+ * 2 MitchellNetravaliFilter(b = a, c = b2) :74-108; 3 LanczosSincFilter(tau = a) :159-185 */
+struct FilterDesc { uint32_t kind; float radius, a, b2; };
+float sinc_abs(float x) { /* LanczosSincFilter::sinc */
+    x = __builtin_fabsf(x);
+    if (x <= 0.00001f) return 1.0f;
+    float pix = PI_F * x;
+    float s = dm_sinf(pix);
+    return s / pix;
+}
+float filter_eval(const FilterDesc& f, float p) {
+    switch (f.kind) {
+    case 1: return __builtin_fabsf(p) > f.radius ? 0.0f : 1.0f;
+    case 2: {
+        const float B = f.a, C = f.b2;
+        float x = __builtin_fabsf(2.0f * p / f.radius);
+        if (x >= 2.0f) return 0.0f;
+        if (x > 1.0f) {
+            float poly = (-B - 6.0f * C) * x * x * x + (6.0f * B + 30.0f * C) * x * x + (-12.0f * B - 48.0f * C) * x + (8.0f * B + 24.0f * C);
+            return poly * (1.0f / 6.0f);
+        }
+        float poly = (12.0f - 9.0f * B - 6.0f * C) * x * x * x + (-18.0f + 12.0f * B + 6.0f * C) * x * x + (6.0f - 2.0f * B);
+        return poly * (1.0f / 6.0f);
+    }
+    case 3: {
+        float x = __builtin_fabsf(p);
+        if (x > f.radius) return 0.0f;
+        float lanczos = sinc_abs(x / f.a);
+        return sinc_abs(x) * lanczos;
+    }
+    default: {
+        const float A0 = 0.35875f, A1 = 0.48829f, A2 = 0.14128f, A3 = 0.01168f;
+        const float TWOPI = PI_F * 2.0f, FOURPI = PI_F * 4.0f, SIXPI = PI_F * 6.0f;
+        if (__builtin_fabsf(p) > f.radius) return 0.0f;
+        float x = __builtin_fabsf(p / f.radius) * 0.5f + 0.5f;
+        return A0 - A1 * dm_cosf(TWOPI * x) + A2 * dm_cosf(FOURPI * x) + A3 * dm_cosf(SIXPI * x);
+    }
+    }
 }
 /* FilterImportanceSampler::new + CDF, src/filter.rs:196-220, src/math.rs:143-190 */
-void build_fis(uint32_t kind, float f_rad, float* inverse_cdf) {
+void build_fis(const FilterDesc& filt, float* inverse_cdf) {
+    const float f_rad = filt.radius;
     const size_t N = RAYN_FIS_TABLE_SIZE;
     std::vector<float> item(N), weight(N), density;
     float weight_sum = 0.0f;
     for (size_t n = 0; n < N; n++) {
         float t = (float)n / (float)(N - 1);
         float d = lerp1(0.0f, f_rad, t);
-        item[n] = d; weight[n] = filter_eval(kind, f_rad, d); weight_sum += weight[n];
+        item[n] = d; weight[n] = filter_eval(filt, d); weight_sum += weight[n];
     }
     for (size_t n = 0; n < N; n++) weight[n] /= weight_sum;
     float cum = 0.0f;
@@ -1068,7 +1099,8 @@ void oracle_build_rd_tables(uint32_t spp, uint32_t sets_1d, uint32_t sets_2d, ui
 void oracle_build_scramble(uint32_t w, uint32_t h, float* out) {
     for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) out[x + (size_t)y * w] = pcg_scramble((uint64_t)(x + y * w));
 }
-void oracle_build_fis_table(uint32_t kind, float radius, float* out) { build_fis(kind, radius, out); }
+void oracle_build_fis_table(uint32_t kind, float radius, float* out) { build_fis(FilterDesc{kind, radius, 0.0f, 0.0f}, out); }
+void oracle_build_fis_table_ex(uint32_t kind, float radius, float a, float b, float* out) { build_fis(FilterDesc{kind, radius, a, b}, out); }
 uint32_t oracle_tile_count(uint32_t w, uint32_t h, uint32_t tw, uint32_t th) { return (uint32_t)build_tiles(w, h, tw, th).size(); }
 
 /* Film::render_frame_into.  tile_subset == NULL renders every tile k with (k + k / tile_step) % tile_step == tile_first

@@ -5,7 +5,7 @@ The compute path is rayn_amd/csrc/librayn_hip.so (hand-written HIP, C ABI in inc
 this package is the thin host mirror.  There is no CPU fallback."""
 from .film import ChannelKind, Context, Film, build_tables  # noqa: F401
 from .params import frame_params  # noqa: F401
-from .scene import (BlackmanHarrisFilter, BoxFilter, BoxFold, CameraStore, Dielectric, Emissive, HitableStore, Lambertian, Linear,  # noqa: F401
+from .scene import (BlackmanHarrisFilter, BoxFilter, LanczosSincFilter, MitchellNetravaliFilter, BoxFold, CameraStore, Dielectric, Emissive, HitableStore, Lambertian, Linear,  # noqa: F401
                     MandelBox, Mandelbulb, MaterialStore, OrthographicCamera, PathTracingIntegrator, PinholeCamera, Sky, Sphere, SphereFold,
                     SphereLight, SphereSDF, Srgb, ThinLensCamera, TracedSDF, VolumeParams, World, vec3)
 from . import setup  # noqa: F401

@@ -58,9 +58,32 @@ float small_rng_first_f32(uint64_t seed) {
     return (float)((uint32_t)out >> 8) * (1.0f / 16777216.0f);
 }
 
-float eval_filter(uint32_t kind, float radius, float p) {
+// Lanczos' sinc, src/filter.rs:159-168
+float lanczos_sinc(float x) {
+    x = x < 0.0f ? -x : x;
+    if (x <= 0.00001f) return 1.0f;
+    const float pix = 3.14159265358979323846f * x;
+    return dm_sinf(pix) / pix;
+}
+
+// Filter::evaluate of the four filters.  p0/p1: Mitchell-Netravali (b, c); LanczosSinc (tau, -).
+float eval_filter(uint32_t kind, float radius, float p0, float p1, float p) {
     float ap = p < 0.0f ? -p : p;
-    if (kind == 1) return ap > radius ? 0.0f : 1.0f; // BoxFilter, src/filter.rs:131-139
+    if (kind == RAYN_FILTER_BOX) return ap > radius ? 0.0f : 1.0f; // BoxFilter, src/filter.rs:131-139
+    if (kind == RAYN_FILTER_MITCHELL) { // MitchellNetravaliFilter::evaluate, src/filter.rs:74-91
+        const float b = p0, c = p1;
+        float x = 2.0f * p / radius;
+        x = x < 0.0f ? -x : x;
+        if (x >= 2.0f) return 0.0f;
+        if (x > 1.0f)
+            return ((-b - 6.0f * c) * x * x * x + (6.0f * b + 30.0f * c) * x * x + (-12.0f * b - 48.0f * c) * x + (8.0f * b + 24.0f * c)) * (1.0f / 6.0f);
+        return ((12.0f - 9.0f * b - 6.0f * c) * x * x * x + (-18.0f + 12.0f * b + 6.0f * c) * x * x + (6.0f - 2.0f * b)) * (1.0f / 6.0f);
+    }
+    if (kind == RAYN_FILTER_LANCZOS) { // LanczosSincFilter::evaluate, src/filter.rs:176-184
+        if (ap > radius) return 0.0f;
+        const float lanczos = lanczos_sinc(ap / p0);
+        return lanczos_sinc(ap) * lanczos;
+    }
     // BlackmanHarrisFilter, src/filter.rs:29-49
     const float pi = 3.14159265358979323846f;
     if (ap > radius) return 0.0f;
@@ -91,14 +114,19 @@ int rayn_build_scramble(uint32_t width, uint32_t height, float* scramble) {
 }
 
 int rayn_build_fis_table(uint32_t filter_kind, float radius, float* table512) {
-    if (!table512 || filter_kind > 1) return RAYN_ERR_INVALID_ARG;
+    if (filter_kind > RAYN_FILTER_BOX) return RAYN_ERR_INVALID_ARG; // the parameterised filters go through _ex
+    return rayn_build_fis_table_ex(filter_kind, radius, 0.0f, 0.0f, table512);
+}
+
+int rayn_build_fis_table_ex(uint32_t filter_kind, float radius, float param0, float param1, float* table512) {
+    if (!table512 || filter_kind > RAYN_FILTER_LANCZOS) return RAYN_ERR_INVALID_ARG;
     const uint32_t N = RAYN_FIS_TABLE_SIZE;
     std::vector<float> pos(N), w(N), cdf(N);
     float sum = 0.0f;
     for (uint32_t n = 0; n < N; n++) { // CDF::insert, src/math.rs:153-156
         float t = (float)n / (float)(N - 1);
         pos[n] = 0.0f * (1.0f - t) + radius * t; // 0.0.lerp(f_rad, t)
-        w[n] = eval_filter(filter_kind, radius, pos[n]);
+        w[n] = eval_filter(filter_kind, radius, param0, param1, pos[n]);
         sum += w[n];
     }
     float run = 0.0f; // CDF::prepare, src/math.rs:158-181

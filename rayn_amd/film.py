@@ -34,11 +34,12 @@ def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter=
     FilterImportanceSampler::new (src/filter.rs:196-220) through the product's host builders."""
     L = lib()
     kind, radius = (0, 1.5) if filter is None else (filter.kind, filter.radius)
+    p0, p1 = getattr(filter, "params", (0.0, 0.0))
     n1, n2 = L.rayn_sets_1d(max_bounces, volume_marches), L.rayn_sets_2d(max_bounces, volume_marches)
     s1, s2 = np.zeros(spp * n1, np.float32), np.zeros(spp * 2 * n2, np.float32)
     scr, fis = np.zeros(width * height, np.float32), np.zeros(_abi.FIS_TABLE_SIZE, np.float32)
     for rc in (L.rayn_build_rd_tables(spp, n1, n2, frame, _fp(s1), _fp(s2)), L.rayn_build_scramble(width, height, _fp(scr)),
-               L.rayn_build_fis_table(kind, radius, _fp(fis))):
+               L.rayn_build_fis_table_ex(kind, radius, p0, p1, _fp(fis))):
         if rc != 0:
             raise RaynHipError(f"table builder failed: {rc}")
     return s1, s2, scr, fis

@@ -342,3 +342,28 @@ class BoxFilter:
     """src/filter.rs:110-140."""
     radius: float = 0.5
     kind: int = 1
+
+
+@dataclass
+class MitchellNetravaliFilter:
+    """src/filter.rs:51-108 (Default: radius 2, b = c = 1/3)."""
+    radius: float = 2.0
+    b: float = 1.0 / 3.0
+    c: float = 1.0 / 3.0
+    kind: int = 2
+
+    @property
+    def params(self):
+        return (self.b, self.c)
+
+
+@dataclass
+class LanczosSincFilter:
+    """src/filter.rs:142-185 (Default: radius 3, tau 3)."""
+    radius: float = 3.0
+    tau: float = 3.0
+    kind: int = 3
+
+    @property
+    def params(self):
+        return (self.tau, 0.0)

@@ -84,3 +84,14 @@ def setup_bulb(resolution=(1920, 1080), volumes=False):
 def setup_s2(resolution=(1920, 1080)):
     """BASELINE config 3: shipped MandelBox scene with the homogeneous volume."""
     return setup(resolution, volumes=True, sdf="mandelbox")
+
+
+def setup_s3(resolution=(7680, 4320)):
+    """BASELINE config 5's scene: S1 seen by a camera whose origin is a closure of time
+    `|t| origin + vel * t` (src/animation.rs:55-68: every packet evaluates it at lane 0's time) -> time-sampled motion blur
+    over the shutter interval.  The reference's TracedSDF itself ignores time (src/sdf.rs:25), so the fractal is static."""
+    from .scene import Linear
+    camera, world = setup(resolution, volumes=False, sdf="mandelbox")
+    cam = world.cameras.get(camera)
+    cam.origin = Linear(cam.origin, vec3(0.9, -0.3, 0.15))
+    return camera, world

@@ -180,6 +180,9 @@ FILM_CASES = [
     ("s1", 32, 32, 1, 3, {"frame": 7, "time_range": (0.5, 0.75)}),  # other frame seed + shutter interval
     ("s1", 32, 16, 1, 2, {"max_marches": 12, "max_vis_marches": 5}),  # march budgets exhausted: 't' is returned as a hit (src/sdf.rs:82)
     ("s1", 32, 16, 1, 2, {"sdf_detail_scale": 2.0, "world_radius": 20.0}),
+    ("s3", 6, 4, 1024, 16, {"tile_size": (2, 2)}),   # config 5's regime: 4096 spp (the supported maximum), 16 bounces, moving camera (motion blur)
+    ("s1", 8, 8, 256, 12, {"tile_size": (4, 4)}),    # config 4's regime: 1024 spp, 12 bounces
+    ("s2", 16, 8, 256, 8, {"tile_size": (4, 4)}),    # config 3's regime: 1024 spp (resolve sorts 1024 keys), 8 bounces, volume; 4x4 tiles keep the oracle fast
 ]
 
 
@@ -369,6 +372,19 @@ def test_box_filter_tables_parity(gpu_ctx, oracle):
     assert film_equal_bits(gpu_ctx.render_host(p, tabs), ref)
 
 
+def test_mitchell_filter_film_parity(gpu_ctx, oracle):
+    """A parameterised filter end to end: B-spline Mitchell-Netravali (b = 1, c = 0; no negative lobe) pixel jitter."""
+    import rayn_amd
+    wd, p = case("s1", 32, 32, 2, 2)
+    filt = rayn_amd.MitchellNetravaliFilter(2.0, 1.0, 0.0)
+    tabs = oracle.build_tables(8, 2, 2, 1, 32, 32, filter_kind=2, filter_radius=2.0, filter_params=(1.0, 0.0))
+    mine = rayn_amd.build_tables(8, 2, 2, 1, 32, 32, filt)
+    assert all(np.array_equal(a, b) for a, b in zip(tabs, mine))
+    ref, _ = oracle.render(wd, p, tabs)
+    gpu_ctx.upload_world(wd)
+    assert film_equal_bits(gpu_ctx.render_host(p, mine), ref)
+
+
 def test_film_class_mirror(oracle):
     """The host mirror with the reference's names: Film::new + render_frame_into + channel access."""
     import rayn_amd as R
@@ -442,3 +458,36 @@ def test_full_size_config2(gpu_ctx, oracle):
     torch.cuda.synchronize()
     for ch in ("color", "alpha", "background", "normal"):
         assert torch.equal(film[ch].view(torch.int32), film2[ch].view(torch.int32)), ch
+
+
+def test_full_size_config3(gpu_ctx):
+    """BASELINE configs[2] (the bench default) at FULL size: 1920x1080, 1024 spp, 8 bounces, volume = 2.12 G paths in 16
+    tile batches.  The CPU oracle needs minutes per 16x16 tile here, so the full-size checks are size-independent
+    properties: path conservation, finite film, and partition independence - one rank's 1/8 share of the tiles
+    (different batching, one worker) must reproduce the full frame's pixels bit for bit.  Bit parity with the oracle in
+    this regime (1024 spp, 8 bounces, volume) is covered at small size by FILM_CASES."""
+    import torch
+    import rayn_amd
+    from rayn_amd.distributed import owned_pixels
+    W, H = 1920, 1080
+    wd, p = case("s2", W, H, 256, 8)
+    tabs = rayn_amd.build_tables(1024, 8, p.volume_marches, p.frame, W, H)
+    gpu_ctx.upload_world(wd)
+    d_tabs = [torch.from_numpy(t).cuda() for t in tabs]
+    film = rayn_amd.film.alloc_device_film(W, H, "cuda:0")
+    gpu_ctx.render_device(p, d_tabs, film)
+    torch.cuda.synchronize()
+    st = gpu_ctx.stats()
+    assert st["paths"] == W * H * 1024 and st["tiles"] == 8160 and st["batches"] >= 2
+    assert st["paths"] <= st["segments"] <= 9 * st["paths"]
+    for ch in ("color", "background", "normal", "alpha"):
+        assert bool(torch.isfinite(film[ch]).all()), ch
+    assert float(film["alpha"].min()) >= 0.0 and float(film["alpha"].max()) <= 1.0
+    wd2, p8 = case("s2", W, H, 256, 8, tile_first=3, tile_step=8)
+    share = rayn_amd.film.alloc_device_film(W, H, "cuda:0")
+    gpu_ctx.render_device(p8, d_tabs, share)
+    torch.cuda.synchronize()
+    idx = torch.from_numpy(owned_pixels(W, H, p.tile_w, p.tile_h, 3, 8)).cuda()
+    assert 0.11 < idx.numel() / (W * H) < 0.14
+    for ch in ("color", "alpha", "background", "normal"):
+        assert torch.equal(film[ch][idx].view(torch.int32), share[ch][idx].view(torch.int32)), ch

@@ -4,6 +4,7 @@ from fractions import Fraction
 from math import isqrt
 
 import numpy as np
+import pytest
 
 import rayn_amd
 
@@ -78,3 +79,29 @@ def test_fis_table_shape():
     assert fis.shape == (512,) and fis[0] == 0.0
     assert np.all(np.diff(fis) >= 0)
     assert fis[-1] <= 1.5 and fis[256] > 0.2 and fis[256] < 0.45  # Blackman-Harris r=1.5 is concentrated near 0
+
+
+@pytest.mark.parametrize("filt,okind,oparams", [
+    ("BlackmanHarrisFilter(1.5)", 0, (0.0, 0.0)), ("BoxFilter(0.5)", 1, (0.0, 0.0)),
+    ("MitchellNetravaliFilter(2.0, 1.0 / 3.0, 1.0 / 3.0)", 2, (1.0 / 3.0, 1.0 / 3.0)), ("MitchellNetravaliFilter(1.5, 1.0, 0.0)", 2, (1.0, 0.0)),
+    ("LanczosSincFilter(3.0, 3.0)", 3, (3.0, 0.0)), ("LanczosSincFilter(1.0, 1.0)", 3, (1.0, 0.0))])
+def test_filter_tables_all_four_filters(filt, okind, oparams):
+    """FilterImportanceSampler::new over the reference's four Filter impls (src/filter.rs:12-185): the product's host
+    builder and the oracle's independent restatement produce the same 512-entry inverse CDF bit for bit."""
+    from oracle import oracle_py as O
+    f = eval("rayn_amd." + filt)
+    mine = rayn_amd.build_tables(4, 0, 2, 1, 4, 4, f)[3]
+    ref = O.build_tables(4, 0, 2, 1, 4, 4, filter_kind=okind, filter_radius=f.radius, filter_params=oparams)[3]
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+    assert mine[0] == 0.0 and np.all(mine >= 0.0) and np.all(mine <= np.float32(f.radius))
+    if okind == 2 and oparams == (1.0, 0.0):  # B-spline (b = 1, c = 0): no negative lobe -> a proper monotone inverse CDF
+        assert np.all(np.diff(mine) >= 0) and mine[-1] > 0.5 * f.radius
+
+
+def test_filter_table_rejects_unknown_kind():
+    import ctypes as C
+    from rayn_amd._lib import lib
+    buf = np.zeros(512, np.float32)
+    fp = buf.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib().rayn_build_fis_table_ex(4, 1.0, 0.0, 0.0, fp) != 0
+    assert lib().rayn_build_fis_table(2, 2.0, fp) != 0  # the parameterised kinds need _ex
