@@ -38,7 +38,10 @@
  *   A6 quasi-rd @ce117035: Roberts R_d, x_k = frac(1/2 + alpha*(offset+1+k)) in exact modular
  *      arithmetic, alpha = phi_d^-j, top 24 bits -> f32.  (Tables are INPUTS to the GPU path.)
  *   A7 rand 0.7.2 SmallRng = Pcg64Mcg; seed_from_u64 = PCG32 expansion; gen::<f32>() =
- *      (next_u32() >> 8) * 2^-24.  (Scrambles are INPUTS to the GPU path.)
+ *      (next_u32() >> 8) * 2^-24.  (Scrambles are INPUTS to the GPU path.)  The two generator
+ *      cores ARE pinned to external known-answer vectors (tests/test_tables.py: rand_pcg's
+ *      Mcg128Xsl64::new(42) outputs, the PCG demo's pcg32_srandom(42, 54) outputs); the seed
+ *      expansion's word order and the float conversion remain assumptions.
  *   A8 f32::signum(+-0) = +-1, NaN -> NaN; `as usize` saturates (NaN -> 0); light indices are
  *      clamped to n_lights-1 where the reference would panic on an out-of-range index.
  */
