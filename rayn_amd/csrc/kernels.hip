@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
 RD bool all_zero(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
+__global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                       uint32_t depth, const uint32_t* __restrict__ bq, uint32_t n_slots, Pool pool, Nee nee,
                                                       uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt, uint32_t ablate,
                                                       unsigned long long* __restrict__ evals_out) {
