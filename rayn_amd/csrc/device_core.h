@@ -220,7 +220,9 @@ RD float div_short(float n, float d) {
 
 template <bool COUNT>
 RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
+#ifndef RAYN_COUNT_FOLDS
     if (COUNT) evals++;
+#endif
     if (h.sdf_kind == RAYN_SDF_MANDELBOX) {
         const f3 offset = p;
         float dr = 1.0f;
@@ -230,6 +232,11 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
         const float frs_eff = mrs <= frs ? frs : -1.0f;
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
+#ifdef RAYN_COUNT_FOLDS /* experiment: the instrumented kernels count sphere-fold block entries (per active lane) instead of evaluations */
+#define RAYN_FOLD_COUNT_HOOK if (COUNT && fold) evals++;
+#else
+#define RAYN_FOLD_COUNT_HOOK
+#endif
 #define RAYN_FOLD_ITER(DIV, BOX)                                                                  \
         {                                                                                     \
             /* box_fold: clamped(-l, l).mul_add(2, -p) */                                     \
@@ -239,17 +246,22 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
             /* sphere_fold: mul = max(1, R2 / max(r2min, r2)).  For r2 >= R2 (and for NaN) the quotient  \
                is <= 1, mul is exactly 1 and the multiplies are identities, so the block only matters for  \
                lanes with r2 < R2, where the quotient is >= 1: max(1, q) == q.  The test is made         \
-               WAVE-UNIFORM (ballot -> scalar branch, block out of line): a per-lane 'if' costs a         \
+               WAVE-UNIFORM (ballot -> scalar branch): a per-lane 'if' costs a         \
                v_cmp + s_and_saveexec + taken s_cbranch_execz per iteration, measured at 15 of the loop's \
-               66 cycles (tools/ubench/fold_rate.hip); inside, lanes that do not fold multiply by 1. */   \
+               66 cycles (tools/ubench/fold_rate.hip); inside, only the folding lanes are enabled.  Measured \
+               (-DRAYN_COUNT_FOLDS): a lane folds in 2.4-2.9 of the 12 iterations, but SOME lane of the   \
+               wave folds in 9-11.7 of them, so this block is part of nearly every iteration. */          \
             const float r2 = mag_sq(p);                                                       \
             const bool fold = r2 < frs_eff;                                                   \
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(fold) != 0, 0)) {                \
+                RAYN_FOLD_COUNT_HOOK                                                          \
                 /* r2 is not NaN on a folding lane: ONE raw v_max_f32 (fmaxf / med3 lower to three, two of  \
                    them canonicalising no-ops) */                                             \
-                const float m = fold ? DIV(frs, vmax_raw(r2, mrs)) : 1.0f;                    \
-                p.x *= m; p.y *= m; p.z *= m;                                                 \
-                dr *= m;                                                                      \
+                if (fold) {                                                                   \
+                    const float m = DIV(frs, vmax_raw(r2, mrs));                              \
+                    p.x *= m; p.y *= m; p.z *= m;                                             \
+                    dr *= m;                                                                  \
+                }                                                                             \
             }                                                                                 \
             p.x = muladd(p.x, s, offset.x);                                                   \
             p.y = muladd(p.y, s, offset.y);                                                   \
@@ -264,6 +276,13 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
             // unrolled by 4 by hand (the ballot is a convergent operation, which stops the loop unroller): the taken
             // back-edge of the rolled loop costs about as much as four VALU operations per iteration
             uint32_t i = 0;
+            if (h.iterations == 12) { // the shipped iteration count (src/setup.rs:44), fully unrolled: another 2 %
+                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
+                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
+                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
+                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
+                i = 12;
+            }
             for (; i + 4 <= h.iterations; i += 4) {
                 RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
                 RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
