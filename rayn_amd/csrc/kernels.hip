@@ -1144,28 +1144,6 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
         r = (float)bad;
         break;
     }
-    case 14: case 15: { // experiment: short division variants b[i] / d over 65536 bit patterns of d from bits(a[i]); returns mismatch count
-        const uint32_t base = __float_as_uint(a[i]);
-        const float n = b[i];
-        uint32_t bad = 0;
-        for (uint32_t j = 0; j < 65536u; j++) {
-            const float d = __uint_as_float(base + j);
-            float q;
-            if (op == 14) { // rcp, mul, one residual correction
-                const float rc = __builtin_amdgcn_rcpf(d);
-                q = n * rc;
-                q = __builtin_fmaf(__builtin_fmaf(-d, q, n), rc, q);
-            } else { // rcp refined once, mul, one residual correction
-                float rc = __builtin_amdgcn_rcpf(d);
-                rc = __builtin_fmaf(__builtin_fmaf(-d, rc, 1.0f), rc, rc);
-                q = n * rc;
-                q = __builtin_fmaf(__builtin_fmaf(-d, q, n), rc, q);
-            }
-            bad += __float_as_uint(q) != __float_as_uint(n / d);
-        }
-        r = (float)bad;
-        break;
-    }
     default: r = a[i] / b[i]; break;
     }
     out[i] = r;
