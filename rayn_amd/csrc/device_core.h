@@ -232,6 +232,14 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
         const float frs_eff = mrs <= frs ? frs : -1.0f;
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
+#ifdef RAYN_ABLATE_FOLD /* timing experiment only (wrong results): never enter the sphere-fold block */
+#define RAYN_FOLD_ENABLE false
+#else
+#define RAYN_FOLD_ENABLE true
+#endif
+#ifndef RAYN_FOLD_BRANCHFREE
+#define RAYN_FOLD_BRANCHFREE 0
+#endif
 #ifdef RAYN_COUNT_FOLDS /* experiment: the instrumented kernels count sphere-fold block entries (per active lane) instead of evaluations */
 #define RAYN_FOLD_COUNT_HOOK if (COUNT && fold) evals++;
 #else
@@ -252,8 +260,14 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
                (-DRAYN_COUNT_FOLDS): a lane folds in 2.4-2.9 of the 12 iterations, but SOME lane of the   \
                wave folds in 9-11.7 of them, so this block is part of nearly every iteration. */          \
             const float r2 = mag_sq(p);                                                       \
-            const bool fold = r2 < frs_eff;                                                   \
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(fold) != 0, 0)) {                \
+            const bool fold = RAYN_FOLD_ENABLE && r2 < frs_eff;                               \
+            if (RAYN_FOLD_BRANCHFREE) {                                                       \
+                /* no control flow at all: every lane divides, non-folding lanes select 1.0 */ \
+                const float q = DIV(frs, vmax_raw(r2, mrs));                                  \
+                const float m = fold ? q : 1.0f;                                              \
+                p.x *= m; p.y *= m; p.z *= m;                                                 \
+                dr *= m;                                                                      \
+            } else if (__builtin_expect(__builtin_amdgcn_ballot_w64(fold) != 0, 0)) {         \
                 RAYN_FOLD_COUNT_HOOK                                                          \
                 /* r2 is not NaN on a folding lane: ONE raw v_max_f32 (fmaxf / med3 lower to three, two of  \
                    them canonicalising no-ops) */                                             \
