@@ -65,6 +65,68 @@ void run(const char* name, float* out) {
     const double wave_iters = (double)blocks * 4 * reps * 12;
     printf("%-44s %7.2f ms  %6.1f cycles/iteration/wave (2.4 GHz x 1024 SIMDs)\n", name, ms, ms * 1e-3 * 2.4e9 * 1024 / wave_iters);
 }
+
+// ILP experiment: NP independent orbits per thread in lock step, realistic sphere fold (exec-masked block with the
+// 4-instruction division) on points near the fractal so that the block is entered in most iterations.
+template <int NP>
+__global__ void __launch_bounds__(256) k_fold_ilp(float* out, int reps, float l, float s, float frs, float mrs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float ox[NP], oy[NP], oz[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        uint32_t hsh = (i * NP + k) * 2654435761u;
+        ox[k] = -2.0f + 4.0f * ((hsh & 1023) / 1023.0f); oy[k] = -2.0f + 4.0f * (((hsh >> 10) & 1023) / 1023.0f); oz[k] = -2.0f + 4.0f * (((hsh >> 20) & 1023) / 1023.0f);
+    }
+    float acc = 0.0f;
+    for (int r = 0; r < reps; r++) {
+        float px[NP], py[NP], pz[NP], dr[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) { px[k] = ox[k]; py[k] = oy[k]; pz[k] = oz[k]; dr[k] = 1.0f; }
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                px[k] = __builtin_fmaf(__builtin_amdgcn_fmed3f(px[k], -l, l), 2.0f, -px[k]);
+                py[k] = __builtin_fmaf(__builtin_amdgcn_fmed3f(py[k], -l, l), 2.0f, -py[k]);
+                pz[k] = __builtin_fmaf(__builtin_amdgcn_fmed3f(pz[k], -l, l), 2.0f, -pz[k]);
+            }
+            float r2[NP];
+            bool fold[NP];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < NP; k++) { r2[k] = px[k] * px[k] + (py[k] * py[k] + pz[k] * pz[k]); fold[k] = r2[k] < frs; any = any || fold[k]; }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+#pragma unroll
+                for (int k = 0; k < NP; k++)
+                    if (fold[k]) {
+                        const float d = r2[k] < mrs ? mrs : r2[k];
+                        const float rc = __builtin_amdgcn_rcpf(d);
+                        float q = frs * rc;
+                        q = __builtin_fmaf(__builtin_fmaf(-d, q, frs), rc, q);
+                        px[k] *= q; py[k] *= q; pz[k] *= q; dr[k] *= q;
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                px[k] = px[k] * s + ox[k]; py[k] = py[k] * s + oy[k]; pz[k] = pz[k] * s + oz[k];
+                dr[k] = -dr[k] * s + 1.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; k++) { acc += px[k] + py[k] + pz[k] + dr[k]; ox[k] += 1e-6f; oy[k] -= 1e-6f; oz[k] += 2e-6f; }
+    }
+    out[i] = acc;
+}
+template <int NP>
+void run_ilp(const char* name, float* out) {
+    const int blocks = 2048, reps = 1000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    k_fold_ilp<NP><<<blocks, 256>>>(out, 10, 1.0f, -2.1f, 3.61f, 1e-4f); hipDeviceSynchronize();
+    hipEventRecord(a); k_fold_ilp<NP><<<blocks, 256>>>(out, reps, 1.0f, -2.1f, 3.61f, 1e-4f); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double wave_iters = (double)blocks * 4 * reps * 12 * NP;
+    printf("%-44s %7.2f ms  %6.1f cycles/iteration/orbit-wave (2.4 GHz x 1024 SIMDs)\n", name, ms, ms * 1e-3 * 2.4e9 * 1024 / wave_iters);
+}
 int main() {
     float* out; hipMalloc(&out, 2048 * 256 * 4);
     run<0>("V0 full body (branch never taken)", out);
@@ -74,5 +136,8 @@ int main() {
     run<4>("V4 branch with unlikely hint", out);
     run<5>("V5 branch-free (always divide, select)", out);
     run<6>("V6 scalar branch on ballot (unlikely)", out);
+    run_ilp<1>("ILP1 near-fractal points, masked fold block", out);
+    run_ilp<2>("ILP2 two orbits per thread", out);
+    run_ilp<3>("ILP3 three orbits per thread", out);
     return 0;
 }
