@@ -74,7 +74,13 @@ typedef struct {
     float sdf_radius;    /* RAYN_SDF_SPHERE radius */
     /* RAYN_HITABLE_SPHERE with a closure transform_seq (TR: Fn(f32) -> Vec3, src/sphere.rs:7, src/animation.rs:62-68):
      * animated != 0 selects the linear closure |t| center + center_vel * t, evaluated — like the reference — at the ray
-     * time of LANE 0 of the packet that calls hit / occluded / get_shading_info. */
+     * time of LANE 0 of the packet that calls hit / occluded / get_shading_info.
+     * EXTENSION for RAYN_HITABLE_TRACED_SDF (the reference's TracedSDF has no transform and ignores time,
+     * src/sdf.rs:12-25): center / animated / center_vel are honoured the same way - the SDF is evaluated in
+     * the frame translated by that origin (hit: ray origin - origin; occluded: both ends - origin;
+     * get_shading_info: normal estimated at point - origin, the shading point stays in world space).  This
+     * is what gives BASELINE config 5 its "animated fractal with time-sampled motion blur".  A zero,
+     * non-animated center (all the reference can express) is an exact no-op. */
     uint32_t animated;
     rayn_vec3 center_vel;
     uint32_t _pad;

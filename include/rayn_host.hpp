@@ -105,7 +105,11 @@ struct Sequenced3 {
 
 struct Sphere { Sequenced3 transform_seq; float radius; MaterialHandle material;
                 static Sphere new_(Sequenced3 c, float r, MaterialHandle m) { return Sphere{c, r, m}; } };
-struct TracedSDF { SDF sdf; MaterialHandle material; static TracedSDF new_(SDF s, MaterialHandle m) { return TracedSDF{std::move(s), m}; } };
+// transform_seq is an EXTENSION (the reference's TracedSDF has none, src/sdf.rs:12-21): Sphere's transform semantics for
+// an SDF - constant or |t| base + vel * t sampled at the packet's lane-0 time; default = the reference's behaviour.
+struct TracedSDF { SDF sdf; MaterialHandle material; Sequenced3 transform_seq;
+                   static TracedSDF new_(SDF s, MaterialHandle m) { return TracedSDF{std::move(s), m, Sequenced3()}; }
+                   static TracedSDF new_moving(SDF s, MaterialHandle m, Sequenced3 tr) { return TracedSDF{std::move(s), m, tr}; } };
 using Hitable = std::variant<Sphere, TracedSDF>;
 
 class HitableStore {
@@ -155,7 +159,8 @@ struct World { // src/world.rs:7-13
                 if (s->transform_seq.animated) { o.animated = 1; o.center_vel = s->transform_seq.vel.pod(); }
             } else {
                 const TracedSDF& t = std::get<TracedSDF>(hitables.items[i]);
-                o.kind = RAYN_HITABLE_TRACED_SDF; o.material = (uint32_t)t.material.idx;
+                o.kind = RAYN_HITABLE_TRACED_SDF; o.material = (uint32_t)t.material.idx; o.center = t.transform_seq.base.pod();
+                if (t.transform_seq.animated) { o.animated = 1; o.center_vel = t.transform_seq.vel.pod(); }
                 if (const MandelBox* m = std::get_if<MandelBox>(&t.sdf)) {
                     o.sdf_kind = RAYN_SDF_MANDELBOX; o.iterations = m->iterations; o.box_side = m->box_fold.side_length;
                     o.min_radius = m->sphere_fold.min_radius; o.fixed_radius = m->sphere_fold.fixed_radius; o.scale = m->scale;

@@ -329,7 +329,19 @@ struct Hitable {
 /* src/sdf.rs:12-102 */
 struct TracedSDF : Hitable {
     std::unique_ptr<SDF> sdf; size_t material; Config cfg;
-    F4 occluded(W3 start, W3 end, F4) const override { /* :25-57 */
+    /* EXTENSION (not in the reference, whose TracedSDF has no transform): a translation of the SDF's frame with
+     * Sphere's transform_seq semantics (src/sphere.rs:8-21, src/animation.rs:62-68): constant, or the closure
+     * |t| center + vel * t sampled at lane 0's time.  Zero constant = the reference's behaviour (x - 0 == x). */
+    V3 center{0, 0, 0}; bool animated = false; V3 center_vel{0, 0, 0};
+    W3 origin_at(F4 time) const {
+        if (!animated) return W3::splat(center);
+        float t = time.v[0];
+        return W3::splat(V3{center.x + center_vel.x * t, center.y + center_vel.y * t, center.z + center_vel.z * t});
+    }
+    F4 occluded(W3 start, W3 end, F4 time) const override { /* :25-57 */
+        W3 frame = origin_at(time);
+        start = start - frame;
+        end = end - frame;
         W3 dir = end - start;
         F4 max_dist = mag(dir);
         dir = dir / max_dist;
@@ -353,11 +365,12 @@ struct TracedSDF : Hitable {
         return merge(hit_mask & !gt_nan_mask, F4(0.0f), F4(1.0f));
     }
     F4 hit(const WRay& ray, F4 t_max, const ThresholdFn& thr) const override { /* :59-83 */
-        F4 dist = sdf->dist(ray.origin);
+        W3 local_origin = ray.origin - origin_at(ray.time);
+        F4 dist = sdf->dist(local_origin);
         F4 t = dist;
         M4 nan_mask = cmp_nan(t, t);
         for (uint32_t m = 0; m < cfg.max_marches; m++) {
-            W3 point = ray.point_at(t);
+            W3 point = mul_add(ray.dir, W3::broadcast(t), local_origin); /* Ray::point_at in the SDF's frame */
             F4 d = sdf->dist(point);
             M4 hit_mask = cmp_lt(abs4(d), fmax4(F4(0.00005f * cfg.detail_scale), F4(0.05f * cfg.detail_scale) * thr(t)));
             M4 gt_mask = cmp_gt(t, t_max);
@@ -377,7 +390,7 @@ struct TracedSDF : Hitable {
     ShadingInfo get_shading_info(const WHit& hit, const ThresholdFn& hps) const override { /* :85-101 */
         W3 point = hit.point();
         F4 half_pixel_size = fmax4(F4(0.0001f), F4(cfg.detail_scale) * hps(hit.t));
-        W3 normal = normal_at(point, half_pixel_size);
+        W3 normal = normal_at(point - origin_at(hit.ray.time), half_pixel_size);
         return ShadingInfo{material, WShadingPoint::make(hit, point, half_pixel_size, normal)};
     }
 };
@@ -695,6 +708,8 @@ struct World {
                 else if (h.sdf_kind == RAYN_SDF_MANDELBULB) { auto s = std::make_unique<Mandelbulb>(); s->iterations = h.iterations; t->sdf = std::move(s); }
                 else { auto s = std::make_unique<SphereSDF>(); s->radius = F4(h.sdf_radius); t->sdf = std::move(s); }
                 t->material = h.material; t->cfg = cfg;
+                t->center = V3{h.center.x, h.center.y, h.center.z}; t->animated = h.animated != 0;
+                t->center_vel = V3{h.center_vel.x, h.center_vel.y, h.center_vel.z};
                 hitables.push_back(std::move(t));
             }
         }

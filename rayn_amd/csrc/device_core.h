@@ -327,9 +327,17 @@ RD Thr make_thr(const DScene& sc, uint32_t depth) {
 }
 RD float thr_at(const Thr& th, float t) { return th.constant ? th.k : th.k * t; }
 
+// Hitable origin at the packet's lane-0 time t0 (closure transform_seq, src/animation.rs:62-68); constants ignore t0.
+// Sphere::transform_seq in the reference (src/sphere.rs:8-21).  EXTENSION: a TracedSDF honours the same field - the SDF
+// is evaluated in the frame translated by this origin (hit: ray origin - origin; occluded: both segment ends - origin;
+// get_shading_info: normal at point - origin, the shading point stays in world space).  A zero constant origin, the
+// only case the reference has, is an exact no-op (x - 0 == x).
+RD f3 sphere_center(const DHitable& h, float t0) { return h.animated ? h.center + h.center_vel * t0 : h.center; }
+
 // TracedSDF::hit, src/sdf.rs:59-83 (per lane; a stopped lane is idempotent in the packet loop)
 template <bool COUNT>
-RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, const Thr& th, uint32_t& evals) {
+RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, const Thr& th, float t0, uint32_t& evals) {
+    o = o - sphere_center(h, t0);
     float t = sdf_dist<COUNT>(h, o, evals);
     const bool nan = t != t;
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
@@ -345,7 +353,10 @@ RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, c
 }
 // TracedSDF::occluded, src/sdf.rs:25-57 (returns 1 = visible, 0 = occluded)
 template <bool COUNT>
-RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, uint32_t& evals) {
+RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, float t0, uint32_t& evals) {
+    const f3 origin = sphere_center(h, t0);
+    start = start - origin;
+    end = end - origin;
     f3 dir = end - start;
     float max_dist = mag(dir);
     dir = div_by_mag(dir, max_dist);
@@ -376,8 +387,6 @@ RD f3 sdf_normal(const DHitable& h, f3 p, float eps, uint32_t& evals) {
 }
 
 // ---- Sphere (src/sphere.rs:23-71) ------------------------------------------------------------------
-// Sphere centre at the packet's lane-0 time t0 (closure transform_seq, src/animation.rs:62-68); constants ignore t0
-RD f3 sphere_center(const DHitable& h, float t0) { return h.animated ? h.center + h.center_vel * t0 : h.center; }
 
 RD float sphere_hit(const DHitable& h, f3 o, f3 d, float t_max, float t0) {
     f3 oc = o - sphere_center(h, t0);
@@ -432,7 +441,7 @@ RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float t0, float
     uint32_t id = OBJ_NONE;
     for (uint32_t k = 0; k < sc.n_hitables; k++) {
         const DHitable& h = sc.h[k];
-        float t = h.kind == RAYN_HITABLE_SPHERE ? sphere_hit(h, o, d, closest, t0) : sdf_hit<COUNT>(sc, h, o, d, closest, th, evals);
+        float t = h.kind == RAYN_HITABLE_SPHERE ? sphere_hit(h, o, d, closest, t0) : sdf_hit<COUNT>(sc, h, o, d, closest, th, t0, evals);
         if (t < closest) { closest = t; id = k; }
     }
     *out_t = closest;
@@ -445,7 +454,7 @@ RD float test_occluded(const DScene& sc, f3 start, f3 end, float t0, uint32_t& e
     for (uint32_t k = 0; k < sc.n_hitables; k++)
         if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], start, end, t0) == 0.0f) return 0.0f;
     for (uint32_t k = 0; k < sc.n_hitables; k++)
-        if (sc.h[k].kind != RAYN_HITABLE_SPHERE && sdf_occluded<COUNT>(sc, sc.h[k], start, end, evals) == 0.0f) return 0.0f;
+        if (sc.h[k].kind != RAYN_HITABLE_SPHERE && sdf_occluded<COUNT>(sc, sc.h[k], start, end, t0, evals) == 0.0f) return 0.0f;
     return 1.0f;
 }
 

@@ -31,7 +31,7 @@ struct DScene {
     DLight l[RAYN_MAX_LIGHTS];
     DCamera cam;
     uint32_t has_scatter, has_extinct; float rho_s, rho_t;
-    uint32_t anim_spheres, _pad_a[3]; // any Sphere with a time-sequenced centre
+    uint32_t anim_spheres, _pad_a[3]; // any hitable (Sphere, or TracedSDF as an extension) with a time-sequenced origin
     // frame constants
     uint32_t width, height, spp, max_bounces, vm, max_marches, max_vis_marches, n1, n2;
     float time_start, time_range, detail_scale, t_max, ndc_x, ndc_y;

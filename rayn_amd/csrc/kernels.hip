@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
         const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)__builtin_ctzll(act));
         const DHitable& h = sc.h[ku];
         if (marching && k == ku) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
-            const f3 p = first ? o : muladd3(d, t, o);
+            const f3 ol = o - sphere_center(h, t0); // the SDF's frame (extension: TracedSDF origin, zero in the reference)
+            const f3 p = first ? ol : muladd3(d, t, ol);
             const float dist = sdf_dist<COUNT>(h, p, evals);
             bool done;
             if (first) { t = dist; nan = dist != dist; first = false; m = 0; done = sc.max_marches == 0; }
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
                         }
                         n_post = closest;
                         n_ids = id | (idp << 8);
+                        n_o = n_o - sphere_center(h, t0); // march in the SDF's frame (extension; zero origin in the reference)
                         n_has = true;
                     }
                 }
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     auto park_job = [&](uint32_t s, f3 a, f3 b) {
         const size_t idx = s * cap + j; // 32 contiguous bytes per segment: one or two HBM sectors per fetch
         nee.job_geo[2 * idx] = make_float4(a.x, a.y, a.z, b.x);
-        nee.job_geo[2 * idx + 1] = make_float4(b.y, b.z, 0.0f, 0.0f);
+        nee.job_geo[2 * idx + 1] = make_float4(b.y, b.z, t0, 0.0f); // t0: the packet time a moving TracedSDF is sampled at
     };
     // analytic spheres of test_occluded (every factor is exactly 0 or 1 -> order independent)
     auto spheres_visible = [&](f3 a, f3 b) {
@@ -594,7 +596,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
         } else { // src/sdf.rs:85-101
             Thr th = make_thr(sc, depth);
             float hps = fmaxs(0.0001f, sc.detail_scale * thr_at(th, t));
-            normal = (ablate & 1u) ? f3{0.0f, 1.0f, 0.0f} : sdf_normal<COUNT>(h, point, hps, evals);
+            normal = (ablate & 1u) ? f3{0.0f, 1.0f, 0.0f} : sdf_normal<COUNT>(h, point - sphere_center(h, t0), hps, evals);
             offset_by = hps;
         }
         vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
@@ -759,12 +761,19 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
     bool exhausted = false;
     bool has = false, first = false, nan = false;
     uint32_t ref = 0, k = 0, m = 0, evals = 0;
-    f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0};
-    float max_dist = 0.0f, t = 0.0f;
+    f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, wa = f3{0, 0, 0}, wb = f3{0, 0, 0};
+    float max_dist = 0.0f, t = 0.0f, jt0 = 0.0f;
     auto next_sdf = [&]() { // advance k to the next TracedSDF; none left -> the segment is visible
         while (k < nh && sc.h[k].kind == RAYN_HITABLE_SPHERE) k++;
         if (k >= nh) { nee.vis[ref] = 1; has = false; }
-        else first = true;
+        else { // the segment in this SDF's frame (TracedSDF::occluded works on start - origin, end - origin)
+            const f3 origin = sphere_center(sc.h[k], jt0);
+            start = wa - origin;
+            dir = (wb - origin) - start;
+            max_dist = mag(dir);
+            dir = div_by_mag(dir, max_dist);
+            first = true;
+        }
     };
     for (;;) {
         const uint64_t idle = __ballot(!has);
@@ -784,11 +793,9 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
                 if (!has && rank < avail) {
                     ref = nee.job_ref[cur + rank]; // [sample][slot]
                     const float4 ja = nee.job_geo[2 * (size_t)ref], jb = nee.job_geo[2 * (size_t)ref + 1];
-                    start = f3{ja.x, ja.y, ja.z};
-                    const f3 e = f3{ja.w, jb.x, jb.y};
-                    dir = e - start;
-                    max_dist = mag(dir);
-                    dir = div_by_mag(dir, max_dist);
+                    wa = f3{ja.x, ja.y, ja.z};
+                    wb = f3{ja.w, jb.x, jb.y};
+                    jt0 = jb.z;
                     k = 0; has = true;
                     next_sdf();
                 }
@@ -860,8 +867,9 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                 if ((need >> lane) & 1ull) if (rank < avail) {
                     n_ref = nee.job_ref[cur + rank];
                     const float4 ja = nee.job_geo[2 * (size_t)n_ref], jb = nee.job_geo[2 * (size_t)n_ref + 1];
-                    n_start = f3{ja.x, ja.y, ja.z};
-                    const f3 e = f3{ja.w, jb.x, jb.y};
+                    const f3 origin = sphere_center(h, jb.z); // TracedSDF origin at the packet time (extension; zero in the reference)
+                    n_start = f3{ja.x, ja.y, ja.z} - origin;
+                    const f3 e = f3{ja.w, jb.x, jb.y} - origin;
                     n_dir = e - n_start;
                     n_max = mag(n_dir);
                     n_dir = div_by_mag(n_dir, n_max);

@@ -152,7 +152,7 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
         if (h.material >= w.n_materials) return fail(ctx, RAYN_ERR_INVALID_ARG, "hitable references a missing material");
         d.kind = h.kind; d.material = h.material; d.sdf_kind = h.sdf_kind; d.iterations = h.iterations;
         d.center = to3(h.center);
-        d.animated = (h.kind == RAYN_HITABLE_SPHERE && h.animated) ? 1u : 0u; d.center_vel = to3(h.center_vel);
+        d.animated = h.animated ? 1u : 0u; d.center_vel = to3(h.center_vel); // Sphere::transform_seq; a TracedSDF's origin as an extension
         if (d.animated) s.anim_spheres = 1;
         d.radius_sq = h.radius * h.radius;
         d.box_l = h.box_side;

@@ -103,8 +103,11 @@ class Sphere:
 
 @dataclass
 class TracedSDF:
+    """TracedSDF::new(sdf, material), src/sdf.rs:17-21.  transform_seq is an EXTENSION with Sphere's semantics (a
+    constant vec3 or Linear(base, vel): `|t| base + vel * t` at the packet's lane-0 time); None = the reference."""
     sdf: object
     material: int
+    transform_seq: object = None
 
 
 class HitableStore(list):
@@ -244,6 +247,12 @@ class World:
                 o.radius = h.radius
             elif isinstance(h, TracedSDF):
                 o.kind = _abi.HITABLE_TRACED_SDF
+                if isinstance(h.transform_seq, Linear):
+                    put(o.center, h.transform_seq.base)
+                    put(o.center_vel, h.transform_seq.vel)
+                    o.animated = 1
+                elif h.transform_seq is not None:
+                    put(o.center, h.transform_seq)
                 s = h.sdf
                 if isinstance(s, MandelBox):
                     o.sdf_kind = _abi.SDF_MANDELBOX

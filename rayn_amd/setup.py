@@ -86,12 +86,17 @@ def setup_s2(resolution=(1920, 1080)):
     return setup(resolution, volumes=True, sdf="mandelbox")
 
 
-def setup_s3(resolution=(7680, 4320)):
+def setup_s3(resolution=(7680, 4320), moving_fractal=True):
     """BASELINE config 5's scene: S1 seen by a camera whose origin is a closure of time
     `|t| origin + vel * t` (src/animation.rs:55-68: every packet evaluates it at lane 0's time) -> time-sampled motion blur
-    over the shutter interval.  The reference's TracedSDF itself ignores time (src/sdf.rs:25), so the fractal is static."""
+    over the shutter interval.  The reference's TracedSDF itself ignores time (src/sdf.rs:25); with moving_fractal the
+    fractal also translates (our TracedSDF.transform_seq extension) - "animated fractal with time-sampled motion blur"."""
     from .scene import Linear
     camera, world = setup(resolution, volumes=False, sdf="mandelbox")
     cam = world.cameras.get(camera)
     cam.origin = Linear(cam.origin, vec3(0.9, -0.3, 0.15))
+    if moving_fractal:  # EXTENSION (rayn_hip.h, rayn_hitable.animated): the fractal itself translates during the shutter
+        for h in world.hitables:
+            if isinstance(h, TracedSDF):
+                h.transform_seq = Linear(vec3(0.0, 0.0, 0.0), vec3(-0.6, 0.45, 0.3))
     return camera, world

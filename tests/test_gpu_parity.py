@@ -337,6 +337,17 @@ def _custom_world(kind, res):
         # a second TracedSDF (sphere SDF) after the MandelBox + one before it: exercises the multi-SDF march paths
         world.hitables.insert(1, R.TracedSDF(R.SphereSDF(0.35), 1))
         world.hitables.push(R.TracedSDF(R.MandelBox(6, R.BoxFold(1.0), R.SphereFold(0.5, 1.0), -2.0), 1))
+    elif kind == "offset_sdf":  # EXTENSION: TracedSDF with a constant origin (the SDF's frame is translated)
+        world.hitables[1].transform_seq = R.vec3(0.35, -0.2, 0.15)
+    elif kind == "moving_sdf":  # EXTENSION: TracedSDF origin as the closure |t| base + vel*t (motion-blurred fractal), volume on
+        cam_h, world = S.setup(res, volumes=True, sdf="mandelbox")
+        world.hitables[1].transform_seq = R.Linear(R.vec3(0.1, 0.0, -0.05), R.vec3(-4.0, 3.0, 2.0))
+    elif kind == "moving_two_sdfs":  # both SDFs of a multi-SDF scene move differently (generic march kernels)
+        world.hitables.insert(1, R.TracedSDF(R.SphereSDF(0.35), 1, R.Linear(R.vec3(1.4, 0.9, 0.6), R.vec3(0.0, -6.0, 0.0))))
+        world.hitables[2].transform_seq = R.Linear(R.vec3(0.0, 0.0, 0.0), R.vec3(3.0, 0.0, -2.0))
+    elif kind == "moving_bulb":
+        cam_h, world = S.setup_bulb(res)
+        world.hitables[1].transform_seq = R.Linear(R.vec3(0.0, 0.05, 0.0), R.vec3(2.0, -1.0, 0.5))
     elif kind == "lambert_sdf_sphere":
         world.hitables[1] = R.TracedSDF(R.SphereSDF(1.0), world.materials.add_material(R.Lambertian(R.Srgb(0.5, 0.5, 0.5))))
     else:
@@ -344,7 +355,8 @@ def _custom_world(kind, res):
     return world.to_desc(cam_h)
 
 
-@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "anim_spheres", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere"])
+@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "anim_spheres", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere",
+                                  "offset_sdf", "moving_sdf", "moving_two_sdfs", "moving_bulb"])
 def test_closed_set_parity(gpu_ctx, oracle, kind):
     from rayn_amd import params as P
     w, h, samples, bounces = 40, 32, 2, 4
