@@ -1,8 +1,12 @@
+# tuning sweep on one rank's share of a workload: usage bash tools/gpu_sweep.sh <workload> <first> <step>
 cd $GRAFT_REPO_ROOT
-run() { echo "== $*"; env "$@" timeout 600 python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-roofline 2>&1 | tail -1 | python -c "
-import json,sys; j=json.loads(sys.stdin.read()); print('VALUE', j['value'], 'ms', j['ms_per_step'])"; }
-run RAYN_HIP_WORKERS=2
-run RAYN_HIP_WORKERS=3
-run RAYN_HIP_WORKERS=4
-run RAYN_HIP_WORKERS=3 RAYN_HIP_PERSISTENT_BLOCKS=1024
-run RAYN_HIP_WORKERS=4 RAYN_HIP_PERSISTENT_BLOCKS=1024
+WL=${1:-c3}; F=${2:-1}; S=${3:-8}
+run() { echo "$* : $(env "$@" python tools/share_profile.py $F $S $WL 2>&1 | tail -1 | sed -E 's/.*ms_extend.: ([0-9.]+).*ms_shade.: ([0-9.]+).*ms_shadow.: ([0-9.]+).*sum ([0-9.]+).*/extend \1 setup \2 shadow \3 sum \4/')"; }
+run X=0
+run RAYN_HIP_PREFETCH_SHADOW=16
+run RAYN_HIP_PREFETCH_SHADOW=48
+run RAYN_HIP_PREFETCH_EXTEND=16
+run RAYN_HIP_PREFETCH_EXTEND=48
+run RAYN_HIP_PERSISTENT_BLOCKS=1536
+run RAYN_HIP_PERSISTENT_BLOCKS=1024
+run RAYN_HIP_PERSISTENT_BLOCKS=4096
