@@ -743,36 +743,51 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
-// Dense list of the pending (sample, slot) pairs: every thread scans SCAN_ITEMS vis bytes, the block
-// scans the counts and reserves its range with ONE atomic (a per-wave append on a single counter
-// saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue").  List order is irrelevant: results are
-// written back by index.
+// Dense list of the pending (sample, slot) pairs.  A block scans 256 * SCAN_ITEMS ids; each wave takes whole 64-id groups
+// (n_slots is a multiple of 64, so a group lies inside one sample and its sample index is wave-uniform: no per-item
+// division), counts its pending items with ballots, the block reserves its range with ONE atomic (a per-wave append on a
+// single counter saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue") and every (wave, group) writes its refs
+// densely in lane order - coalesced 256-byte stores, and consecutive list entries point at consecutive segments, which
+// keeps the shadow kernel's fetch contiguous.  List order is irrelevant to the result: it is written back by index.
 constexpr uint32_t SCAN_ITEMS = 16;
 __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, uint32_t n_slots, uint32_t* __restrict__ job_count) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     const uint32_t n_ids = ns * n_slots;
     const size_t cap = nee.cap;
-    const uint32_t first = blockIdx.x * (256 * SCAN_ITEMS) + threadIdx.x;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t block_first = blockIdx.x * (256 * SCAN_ITEMS);
     uint32_t refs[SCAN_ITEMS];
-    uint32_t cnt = 0;
+    uint32_t wave_total = 0; // wave-uniform
 #pragma unroll
     for (uint32_t r = 0; r < SCAN_ITEMS; r++) {
-        const uint32_t id = first + r * 256;
+        const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(block_first + (r * 4 + wave) * 64)); // first id of the group
         refs[r] = INVALID;
-        if (id < n_ids) {
-            const uint32_t ref = (uint32_t)((id / n_slots) * cap + (id % n_slots)); // < 2^32, checked on the host
-            if (nee.vis[ref] == 2) { refs[r] = ref; cnt++; }
+        if (g < n_ids) {
+            const uint32_t s = g / n_slots;                                   // scalar
+            const uint32_t ref = (uint32_t)(s * cap + (g - s * n_slots) + lane); // < 2^32, checked on the host
+            if (nee.vis[ref] == 2) refs[r] = ref;
         }
+        wave_total += (uint32_t)__popcll(__ballot(refs[r] != INVALID));
     }
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(cnt, s_wave, &tot);
+    if (lane == 0) s_wave[wave] = wave_total;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t wt = s_wave[w];
+        if (w < wave) before += wt;
+        tot += wt;
+    }
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(job_count, tot) : 0u;
     __syncthreads();
-    uint32_t w = s_base + ex;
+    uint32_t w = s_base + before;
 #pragma unroll
-    for (uint32_t r = 0; r < SCAN_ITEMS; r++)
-        if (refs[r] != INVALID) nee.job_ref[w++] = refs[r];
+    for (uint32_t r = 0; r < SCAN_ITEMS; r++) {
+        const uint64_t m = __ballot(refs[r] != INVALID);
+        if (refs[r] != INVALID) nee.job_ref[w + mbcnt(m)] = refs[r];
+        w += (uint32_t)__popcll(m);
+    }
 }
 
 // TracedSDF::occluded (src/sdf.rs:25-57) for the pending shadow segments, persistent waves (see k_extend).
