@@ -54,3 +54,21 @@ def test_create_without_gpu_is_an_error_not_a_fallback(L):
     import rayn_amd
     with pytest.raises(rayn_amd.film.RaynHipError):
         rayn_amd.Context(0)
+
+
+def test_traced_sdf_transform_maps_to_the_hitable_fields():
+    """EXTENSION plumbing (host logic, no GPU): TracedSDF.transform_seq -> rayn_hitable.center / animated / center_vel,
+    and the default keeps the reference's zero, non-animated origin."""
+    import rayn_amd as R
+    from rayn_amd import setup as S
+    cam, world = S.setup_s1((32, 32))
+    d = world.to_desc(cam)
+    sdf = [h for h in d.hitables[: d.n_hitables] if h.kind == R._abi.HITABLE_TRACED_SDF]
+    assert len(sdf) == 1 and sdf[0].animated == 0 and (sdf[0].center.x, sdf[0].center.y, sdf[0].center.z) == (0.0, 0.0, 0.0)
+    cam, world = S.setup_s3((32, 32))
+    d = world.to_desc(cam)
+    sdf = [h for h in d.hitables[: d.n_hitables] if h.kind == R._abi.HITABLE_TRACED_SDF][0]
+    assert sdf.animated == 1 and abs(sdf.center_vel.x + 0.6) < 1e-6 and d.camera.animated & 1
+    world.hitables[1].transform_seq = R.vec3(0.5, 0.25, -1.0)
+    sdf = [h for h in world.to_desc(cam).hitables[:8] if h.kind == R._abi.HITABLE_TRACED_SDF][0]
+    assert sdf.animated == 0 and (sdf.center.x, sdf.center.y, sdf.center.z) == (0.5, 0.25, -1.0)
