@@ -1,0 +1,51 @@
+"""One-off hunt for rare GPU/oracle mismatches: N seeded random scenes (the generator of tests/test_gpu_parity.py's
+test_randomised_scene_parity, larger films).  usage: fuzz_parity.py [n=60] [first_seed=100]"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+import rayn_amd as R
+from rayn_amd import setup as S, params as P
+from oracle import oracle_py as O
+from common import film_equal_bits, film_l2
+n, first = (int(sys.argv[1]) if len(sys.argv) > 1 else 60), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+ctx = R.Context(0)
+bad = 0
+t_start = time.time()
+for seed in range(first, first + n):
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(32, 97)), int(rng.integers(24, 65))
+    volumes = bool(rng.integers(0, 2))
+    kind = rng.choice(["mandelbox", "mandelbox", "mandelbox", "mandelbulb", "sphere"])
+    cam_h, world = S.setup((w, h), volumes=volumes, sdf=str(kind))
+    if kind == "mandelbox":
+        box = world.hitables[1].sdf
+        box.iterations = int(rng.integers(4, 16))
+        box.scale = float(np.float32(rng.uniform(-2.8, -1.6) if rng.integers(0, 2) else rng.uniform(1.7, 3.0)))
+        box.box_fold.side_length = float(np.float32(rng.uniform(0.6, 1.5)))
+        box.sphere_fold.min_radius = float(np.float32(rng.uniform(0.002, 0.7)))
+        box.sphere_fold.fixed_radius = float(np.float32(rng.uniform(0.75, 2.5)))
+    if volumes:
+        world.volume_params = R.VolumeParams(float(np.float32(rng.uniform(0.02, 0.8))), float(np.float32(rng.uniform(0.005, 0.3))))
+    for L in world.lights:
+        L.pos = L.pos + rng.uniform(-0.4, 0.4, 3).astype(np.float32)
+    cam = world.cameras.get(cam_h)
+    cam.origin = (cam.origin * np.float32(rng.uniform(0.4, 1.6)) + rng.uniform(-0.6, 0.6, 3).astype(np.float32)).astype(np.float32)
+    if rng.integers(0, 3) == 0:
+        world.hitables[1].transform_seq = R.Linear(rng.uniform(-0.3, 0.3, 3).astype(np.float32), rng.uniform(-4, 4, 3).astype(np.float32))
+    if rng.integers(0, 4) == 0:
+        cam.origin = R.Linear(cam.origin, rng.uniform(-3, 3, 3).astype(np.float32))
+    wd = world.to_desc(cam_h)
+    samples, bounces = int(rng.integers(1, 5)), int(rng.integers(0, 9))
+    t0 = float(np.float32(rng.uniform(0.0, 3.0)))
+    p = P.frame_params(w, h, samples, bounces, frame=int(rng.integers(1, 200)), time_range=(t0, float(np.float32(t0 + rng.uniform(0.005, 0.3)))),
+                       tile_size=(int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))), volume_marches=int(rng.choice([2, 2, 3, 4])))
+    tabs = O.build_tables(4 * samples, bounces, p.volume_marches, p.frame, w, h)
+    ref, ctr = O.render(wd, p, tabs)
+    ctx.upload_world(wd)
+    out = ctx.render_host(p, tabs)
+    st = ctx.stats()
+    ok = st["paths"] == ctr.paths and st["segments"] == ctr.segments and film_equal_bits(out, ref)
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed {seed}: {kind} {w}x{h} spp {4*samples} B {bounces} vol {volumes} L2 {film_l2(out, ref)} segs {st['segments']} vs {ctr.segments}", flush=True)
+print(f"{n} scenes, {bad} mismatches, {time.time() - t_start:.1f} s")
