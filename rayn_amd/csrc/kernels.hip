@@ -1042,27 +1042,33 @@ RD uint32_t count_valid_lds(const K* key, uint32_t n, K none) {
     return c;
 }
 
-// serial float sum of src[0..cnt) in index order (one lane = one channel); loads are issued eight at a time
-RD float serial_sum(const float* src, uint32_t cnt) {
+// serial float sum of src[0], src[stride], .. (cnt terms) in index order (one lane = one channel); loads are issued eight at a time
+RD float serial_sum(const float* src, uint32_t stride, uint32_t cnt) {
     float a = 0.0f;
     uint32_t e = 0;
     for (; e + 8 <= cnt; e += 8) {
-        const float4 v0 = *(const float4*)(src + e), v1 = *(const float4*)(src + e + 4);
-        a += v0.x; a += v0.y; a += v0.z; a += v0.w;
-        a += v1.x; a += v1.y; a += v1.z; a += v1.w;
+        float v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) v[u] = src[(e + u) * stride];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) a += v[u];
     }
-    for (; e < cnt; e++) a += src[e];
+    for (; e < cnt; e++) a += src[e * stride];
     return a;
 }
 
+// LDS: 16 bytes per sort slot.  [0, 8n): the u64 keys of the colour pass, overwritten IN PLACE (by the lane that owns
+// the slot) with the sample's (r, g) once it is sorted; [8n, 16n): (b, background flag) pairs, later the u32 keys of the
+// AOV pass plus the normals' z.  (28 bytes per slot left one wave per CU at 4096 spp and made the sorts latency-bound.)
 __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
                                                  float* __restrict__ out_color, float* __restrict__ out_alpha,
                                                  float* __restrict__ out_background, float* __restrict__ out_normal, uint32_t n_sort) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem64[];
-    unsigned long long* key = smem64;              // [n_sort] depth:7 | slot:32 | background:1 | sample:12
-    uint8_t* flg = (uint8_t*)(smem64 + n_sort);    // [n_sort] 1 = Background sample (4 bytes per entry reserved)
-    uint32_t* key32 = (uint32_t*)flg + n_sort;     // [n_sort] object:16 | sample:16
-    float* stage = (float*)(key32 + n_sort);       // [3][n_sort] values in accumulation order
+    unsigned long long* key = smem64;            // [n_sort] depth:7 | slot:32 | background:1 | sample:12
+    float2* rg = (float2*)smem64;                // the same slots after staging
+    float2* bf = (float2*)(smem64 + n_sort);     // [n_sort] (b, flag bits)
+    uint32_t* key32 = (uint32_t*)(smem64 + n_sort); // [n_sort] object:16 | sample:16 (AOV pass)
+    float* nz = (float*)(smem64 + n_sort) + n_sort; // [n_sort] normal.z (AOV pass)
     constexpr unsigned long long NOKEY = ~0ull;
     const DScene& sc = *scp;
     const DTile tile = tiles[blockIdx.y];
@@ -1086,31 +1092,34 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
     __syncthreads();
     if (!is_sorted_lds(key, n_sort)) bitonic_sort_lds(key, n_sort); // sky-only pixels arrive sorted
     const uint32_t cnt = count_valid_lds(key, n_sort, NOKEY);
+    __syncthreads();
     for (uint32_t e = threadIdx.x; e < cnt; e += 64) {
         const uint32_t lo = (uint32_t)key[e];
         const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
-        stage[e] = c.x; stage[n_sort + e] = c.y; stage[2 * n_sort + e] = c.z;
-        flg[e] = (uint8_t)((lo >> 12) & 1u);
+        rg[e] = make_float2(c.x, c.y);
+        bf[e] = make_float2(c.z, __uint_as_float((lo >> 12) & 1u));
     }
     __syncthreads();
     if (threadIdx.x < 3) {
-        const float* src = stage + threadIdx.x * n_sort;
+        const float* src = threadIdx.x < 2 ? (const float*)rg + threadIdx.x : (const float*)bf; // stride 2 floats
+        const uint32_t* flg = (const uint32_t*)bf + 1;
         float c = 0.0f, b = 0.0f;
         uint32_t e = 0;
         for (; e + 8 <= cnt; e += 8) {
-            const float4 v0 = *(const float4*)(src + e), v1 = *(const float4*)(src + e + 4);
-            const uint2 f = *(const uint2*)(flg + e);
-            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            float v[8];
+            uint32_t f[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++) {
-                const bool bg = (((u < 4 ? f.x : f.y) >> (8 * (u & 3))) & 1u) != 0;
+                const bool bg = f[u] != 0;
                 const float s = (bg ? b : c) + v[u];
                 b = bg ? s : b;
                 c = bg ? c : s;
             }
         }
         for (; e < cnt; e++) {
-            if (flg[e]) b += src[e]; else c += src[e];
+            if (flg[2 * e]) b += src[2 * e]; else c += src[2 * e];
         }
         out_color[3 * fi + threadIdx.x] = c / n;
         out_background[3 * fi + threadIdx.x] = b / n;
@@ -1125,14 +1134,17 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
     __syncthreads();
     if (!is_sorted_lds(key32, n_sort)) bitonic_sort_lds(key32, n_sort);
     const uint32_t cnt0 = count_valid_lds(key32, n_sort, INVALID);
+    __syncthreads();
     for (uint32_t e = threadIdx.x; e < cnt0; e += 64) {
         const float4 a = pool.aov[P0 + (key32[e] & 0xFFFFu)];
-        stage[e] = a.x; stage[n_sort + e] = a.y; stage[2 * n_sort + e] = a.z;
+        rg[e] = make_float2(a.x, a.y);
+        nz[e] = a.z;
     }
     __syncthreads();
     // Alpha adds 1.0 per depth-0 surface sample: every partial sum is an integer < 2^24, so the serial sum is the count
     if (threadIdx.x == 3) out_alpha[fi] = (float)cnt0 / n;
-    else if (threadIdx.x < 3) out_normal[3 * fi + threadIdx.x] = serial_sum(stage + threadIdx.x * n_sort, cnt0) / n;
+    else if (threadIdx.x < 2) out_normal[3 * fi + threadIdx.x] = serial_sum((const float*)rg + threadIdx.x, 2, cnt0) / n;
+    else if (threadIdx.x == 2) out_normal[3 * fi + 2] = serial_sum(nz, 1, cnt0) / n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1276,7 +1288,7 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {
     uint32_t n_sort = 8;
     while (n_sort < spp) n_sort <<= 1;
-    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 28, s, sc, tiles, pool, out_color, out_alpha, out_background,
+    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 16, s, sc, tiles, pool, out_color, out_alpha, out_background,
                        out_normal, n_sort);
 }
 void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {
