@@ -35,7 +35,9 @@ for seed in range(first, first + n):
     if rng.integers(0, 4) == 0:
         cam.origin = R.Linear(cam.origin, rng.uniform(-3, 3, 3).astype(np.float32))
     wd = world.to_desc(cam_h)
-    samples, bounces = int(rng.integers(1, 5)), int(rng.integers(0, 9))
+    samples, bounces = int(rng.choice([1, 2, 3, 4, 4, 8, 16, 33, 64, 150])), int(rng.integers(0, 9))
+    if samples >= 8:  # many samples per pixel (the resolve sorts 4*samples keys): keep the film small
+        w, h = max(8, w // (samples // 4 + 1)), max(6, h // 4)
     t0 = float(np.float32(rng.uniform(0.0, 3.0)))
     p = P.frame_params(w, h, samples, bounces, frame=int(rng.integers(1, 200)), time_range=(t0, float(np.float32(t0 + rng.uniform(0.005, 0.3)))),
                        tile_size=(int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))), volume_marches=int(rng.choice([2, 2, 3, 4])))
