@@ -61,42 +61,53 @@
 namespace {
 
 /* ------------------------------------------------------------------ f32x4 (wide 0.4.6) ---- */
+/* f32x4 as a real SSE vector (GCC vector extension): packed IEEE operations give each lane exactly the scalar result, and the
+ * CPU baseline this file also serves as is then SIMD like the reference's `wide` f32x4 rather than four scalar lanes. */
+typedef float f4v __attribute__((vector_size(16)));
+typedef int i4v __attribute__((vector_size(16)));
 struct F4 {
-    float v[4];
-    F4() : v{0, 0, 0, 0} {}
-    F4(float s) : v{s, s, s, s} {}
-    F4(float a, float b, float c, float d) : v{a, b, c, d} {}
+    union { f4v q; float v[4]; };
+    F4() : q{0, 0, 0, 0} {}
+    F4(float s) : q{s, s, s, s} {}
+    F4(float a, float b, float c, float d) : q{a, b, c, d} {}
+    explicit F4(f4v x) : q(x) {}
     float& operator[](int i) { return v[i]; }
     float operator[](int i) const { return v[i]; }
 };
-struct M4 { /* lane mask (comparison result) */
-    bool v[4];
-    int move_mask() const { return (v[0] ? 1 : 0) | (v[1] ? 2 : 0) | (v[2] ? 4 : 0) | (v[3] ? 8 : 0); }
+struct M4 { /* lane mask (comparison result): all-ones / all-zeros per lane */
+    union { i4v q; int v[4]; };
+    M4() : q{0, 0, 0, 0} {}
+    explicit M4(i4v x) : q(x) {}
+    int move_mask() const { return __builtin_ia32_movmskps((f4v)q); }
 };
-#define F4OP(op) \
-    inline F4 operator op(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
-F4OP(+) F4OP(-) F4OP(*) F4OP(/)
-#undef F4OP
-inline F4 operator-(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = -a.v[i]; return r; }
+inline F4 operator+(F4 a, F4 b) { return F4(a.q + b.q); }
+inline F4 operator-(F4 a, F4 b) { return F4(a.q - b.q); }
+inline F4 operator*(F4 a, F4 b) { return F4(a.q * b.q); }
+inline F4 operator/(F4 a, F4 b) { return F4(a.q / b.q); }
+inline F4 operator-(F4 a) { return F4((f4v)((i4v)a.q ^ (i4v){(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000})); } /* sign flip, also of zero / NaN */
 inline F4& operator+=(F4& a, F4 b) { a = a + b; return a; }
 inline F4& operator*=(F4& a, F4 b) { a = a * b; return a; }
 inline F4& operator/=(F4& a, F4 b) { a = a / b; return a; }
-#define M4OP(name, expr) \
-    inline M4 name(F4 a, F4 b) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = (expr); return r; }
-M4OP(cmp_lt, a.v[i] < b.v[i]) M4OP(cmp_le, a.v[i] <= b.v[i]) M4OP(cmp_gt, a.v[i] > b.v[i])
-M4OP(cmp_eq, a.v[i] == b.v[i]) M4OP(cmp_nan, (a.v[i] != a.v[i]) || (b.v[i] != b.v[i]))
-#undef M4OP
-inline M4 operator|(M4 a, M4 b) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
-inline M4 operator&(M4 a, M4 b) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
-inline M4 operator!(M4 a) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
-inline F4 merge(M4 m, F4 t, F4 f) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? t.v[i] : f.v[i]; return r; }
-/* A2: SSE semantics */
-inline F4 fmax4(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i]; return r; }
-inline F4 fmin4(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
-inline F4 abs4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = __builtin_fabsf(a.v[i]); return r; }
-inline F4 sqrt4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = __builtin_sqrtf(a.v[i]); return r; }
+inline M4 cmp_lt(F4 a, F4 b) { return M4(a.q < b.q); }
+inline M4 cmp_le(F4 a, F4 b) { return M4(a.q <= b.q); }
+inline M4 cmp_gt(F4 a, F4 b) { return M4(a.q > b.q); }
+inline M4 cmp_eq(F4 a, F4 b) { return M4(a.q == b.q); }
+inline M4 cmp_nan(F4 a, F4 b) { return M4((a.q != a.q) | (b.q != b.q)); }
+inline M4 operator|(M4 a, M4 b) { return M4(a.q | b.q); }
+inline M4 operator&(M4 a, M4 b) { return M4(a.q & b.q); }
+inline M4 operator!(M4 a) { return M4(~a.q); }
+inline F4 merge(M4 m, F4 t, F4 f) { return F4((f4v)(((i4v)t.q & m.q) | ((i4v)f.q & ~m.q))); }
+/* A2: SSE semantics: maxps(a, b) = a > b ? a : b (b when unordered or equal), minps likewise */
+inline F4 fmax4(F4 a, F4 b) { return F4(__builtin_ia32_maxps(a.q, b.q)); }
+inline F4 fmin4(F4 a, F4 b) { return F4(__builtin_ia32_minps(a.q, b.q)); }
+inline F4 abs4(F4 a) { return F4((f4v)((i4v)a.q & (i4v){0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff})); }
+inline F4 sqrt4(F4 a) { return F4(__builtin_ia32_sqrtps(a.q)); }
 inline F4 floor4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = __builtin_floorf(a.v[i]); return r; }
-inline F4 mul_add(F4 a, F4 b, F4 c) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = rayn_muladd(a.v[i], b.v[i], c.v[i]); return r; } /* A1 */
+#if RAYN_FMA_POLICY
+inline F4 mul_add(F4 a, F4 b, F4 c) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = rayn_muladd(a.v[i], b.v[i], c.v[i]); return r; } /* A1, fused build */
+#else
+inline F4 mul_add(F4 a, F4 b, F4 c) { return F4(a.q * b.q + c.q); } /* A1: unfused (-ffp-contract=off keeps it two roundings) */
+#endif
 inline float signum1(float x) { return x != x ? x : __builtin_copysignf(1.0f, x); } /* A8 */
 inline F4 signum4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = signum1(a.v[i]); return r; }
 inline F4 exp4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = dm_expf(a.v[i]); return r; }
