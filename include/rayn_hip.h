@@ -178,6 +178,7 @@ typedef struct {
     uint64_t queue_bytes_bin;     /* algorithmic HBM bytes of the bin stage */
     double ms_shadow, ms_finish; /* k_shadow, k_shade_finish */
     uint64_t queue_bytes_compact; /* algorithmic HBM bytes of the repack stage */
+    uint64_t shadow_jobs;         /* shadow segments marched by k_shadow (37 algorithmic bytes each: 4 ref + 32 segment in, 1 visibility out) */
 } rayn_stats;
 
 typedef struct rayn_ctx rayn_ctx;
@@ -205,9 +206,10 @@ int rayn_hip_render_frame(rayn_ctx* ctx, const rayn_frame_params* p,
                           float* out_normal);
 
 /* Same, but every pointer is a DEVICE pointer on the ctx's GPU and the work is enqueued on
- * 'hip_stream' (a hipStream_t; NULL = the ctx's own stream).  Returns after the last kernel has
- * been enqueued and the per-depth queue counts have been consumed (the call synchronises the
- * stream internally once per depth).  This is the entry the bench and the RCCL path use. */
+ * 'hip_stream' (a hipStream_t; NULL = the ctx's own stream), after everything already queued there.
+ * The call is BLOCKING: it returns when the frame is complete (it waits once, at the end, to read the
+ * frame statistics back; the depth loop itself never synchronises - queue sizes stay on the device).
+ * This is the entry the bench and the multi-GPU paths use. */
 int rayn_hip_render_frame_device(rayn_ctx* ctx, const rayn_frame_params* p,
                                  const float* d_samples_1d, const float* d_samples_2d,
                                  const float* d_scramble, const float* d_fis_table,
@@ -261,6 +263,12 @@ int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy);
 /* sizeof() of the ABI structs as compiled: 0 world_desc, 1 frame_params, 2 stats, 3 hitable,
  * 4 material, 5 light, 6 camera — lets a binding verify its layout. */
 size_t rayn_hip_sizeof(int which);
+
+/* Restrict the following renders to the listed tiles (indices in the reference's tile order, src/film.rs:399-427; duplicates
+ * and out-of-range indices are an error); n = 0 clears the restriction.  While a subset is set tile_first/tile_step are
+ * ignored.  Tiles are independent (src/film.rs:439-627), so a subset render produces exactly the pixels the full frame
+ * would: the parity tests use it to compare whole 16x16 tiles at the full BASELINE configurations with oracle digests. */
+int rayn_hip_set_tile_subset(rayn_ctx* ctx, const uint32_t* tiles, uint32_t n);
 
 /* Packet-order dump of ONE tile of the next renders (diagnostics; tile_index in the reference's tile order, -1 = off):
  * after every depth's bin stage the tile's binned queue is read back as records of 6 u32 {depth, object, tile x,

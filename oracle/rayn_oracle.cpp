@@ -337,6 +337,12 @@ struct Hitable {
     virtual ShadingInfo get_shading_info(const WHit& hit, const ThresholdFn& hps) const = 0;
 };
 
+/* DIAGNOSTICS (tools/coherence_sim.cpp only; never set by the tests): when a sink is installed through
+ * oracle_set_shadow_sink, every lane of every TracedSDF::occluded call appends {depth, NEE sample index, start.xyz, end.xyz}.
+ * Single-threaded use (render one tile with threads = 1). */
+static std::vector<float>* g_shadow_sink = nullptr;
+static float g_sink_depth = 0.0f, g_sink_sample = 0.0f;
+
 /* src/sdf.rs:12-102 */
 struct TracedSDF : Hitable {
     std::unique_ptr<SDF> sdf; size_t material; Config cfg;
@@ -353,6 +359,11 @@ struct TracedSDF : Hitable {
         W3 frame = origin_at(time);
         start = start - frame;
         end = end - frame;
+        if (g_shadow_sink)
+            for (int i = 0; i < 4; i++) {
+                const float rec[8] = {g_sink_depth, g_sink_sample, start.x.v[i], start.y.v[i], start.z.v[i], end.x.v[i], end.y.v[i], end.z.v[i]};
+                g_shadow_sink->insert(g_shadow_sink->end(), rec, rec + 8);
+            }
         W3 dir = end - start;
         F4 max_dist = mag(dir);
         dir = dir / max_dist;
@@ -820,6 +831,7 @@ struct Integrator {
             F4 correction_factor((float)nl / 4.0f);
             for (size_t i = 0; i < 4; i++) {
                 size_t light_idx = light_index(lts.v[i], nl);
+                g_sink_depth = (float)depth; g_sink_sample = (float)i;
                 WSrgb li = surface_sample_one_light(world, light_idx, &samples_2d[0 + i * 2], isect, bsdf);
                 isect.ray.radiance += li * isect.ray.throughput * correction_factor * volume_transmission;
             }
@@ -832,6 +844,7 @@ struct Integrator {
                 for (size_t i = 0; i < 4; i++) {
                     size_t light_idx = light_index(lts.v[i], nl);
                     F4 t;
+                    g_sink_depth = (float)depth; g_sink_sample = (float)(4 + 4 * march + i);
                     WSrgb li = volume_sample_one_light(world, light_idx, &samples_2d[8 + 8 * march + i * 2], samples_1d[1],
                                                        isect.ray.origin, isect.ray.dir, isect.t, isect.ray.time, &t);
                     F4 transmission = world.has_extinct ? exp4(F4(-world.rho_t) * t) : F4(1.0f);
@@ -1238,5 +1251,17 @@ void oracle_detmath(uint32_t op, const float* a, const float* b, float* out, uin
     }
 }
 int oracle_fma_policy() { return RAYN_FMA_POLICY; }
+/* DIAGNOSTICS: install (on != 0) / remove the shadow-segment sink; oracle_take_shadow_sink copies up to cap floats (records of 8)
+ * and returns the float count.  Used by tools/coherence_sim.py to study wave coherence of the shadow marches on the CPU. */
+void oracle_set_shadow_sink(int on) {
+    delete g_shadow_sink;
+    g_shadow_sink = on ? new std::vector<float>() : nullptr;
+}
+uint64_t oracle_take_shadow_sink(float* out, uint64_t cap) {
+    if (!g_shadow_sink) return 0;
+    const uint64_t n = g_shadow_sink->size();
+    if (out) memcpy(out, g_shadow_sink->data(), (size_t)std::min(n, cap) * 4);
+    return n;
+}
 
 } // extern "C"

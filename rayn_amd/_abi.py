@@ -62,7 +62,7 @@ class Stats(C.Structure):
                 ("ms_raygen", C.c_double), ("ms_extend", C.c_double), ("ms_bin", C.c_double),
                 ("ms_shade", C.c_double), ("ms_compact", C.c_double), ("ms_resolve", C.c_double),
                 ("launches_extend", C.c_uint64), ("launches_shade", C.c_uint64), ("queue_bytes_bin", C.c_uint64),
-                ("ms_shadow", C.c_double), ("ms_finish", C.c_double), ("queue_bytes_compact", C.c_uint64)]
+                ("ms_shadow", C.c_double), ("ms_finish", C.c_double), ("queue_bytes_compact", C.c_uint64), ("shadow_jobs", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -37,6 +37,21 @@ struct Nee {
     size_t jobcap;
 };
 
+// Device-resident queue sizes and counters of one worker.  The depth loop never reads a queue size back to the host: every
+// kernel takes its element count from here, grids are sized for the batch's upper bound and loop (grid-stride) or exit.
+struct DCtl {
+    uint32_t q_groups;     // ray queue size in 64-slot groups   (k_raygen, then k_tile_prefix of the repack)
+    uint32_t q_valid;      // valid entries in it
+    uint32_t b_groups;     // binned queue size in groups        (k_tile_prefix of the bin stage)
+    uint32_t b_valid;      // hits = valid binned entries
+    uint32_t head_extend;  // persistent-kernel queue heads, reset on device between uses
+    uint32_t job_count;    // pending shadow segments of this depth (k_shadow_list)
+    uint32_t head_shadow;
+    uint32_t _pad;
+    // statistics of the whole frame share (read back once, at the end)
+    unsigned long long segments, shaded_slots, entries_sum, next_sum, shadow_jobs, _pad2;
+};
+
 // the host brackets the three shading kernels with its profiling events through these hooks
 struct ShadeHooks {
     void* user;
@@ -74,21 +89,24 @@ struct Tables {
     using namespace rayn;                                                                          \
     void launch_pack_tables(hipStream_t s, Tables tab, float4* out, uint32_t spp, uint32_t depths, uint32_t n1, uint32_t n2); \
     void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile, \
-                       Pool pool, uint32_t* q, uint32_t n_pool);                                    \
-    void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool, \
-                       uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, uint32_t* head, unsigned long long* evals, const Tuning& tun); \
+                       Pool pool, uint32_t* q, uint32_t n_pool, DCtl* ctl);                         \
+    void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t max_entries, Pool pool, \
+                       uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun); \
     void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt, \
                           const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total, \
-                          uint32_t* tile_valid);                                                    \
+                          uint32_t* tile_valid, uint32_t* tile_cls_cnt);                            \
     void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base, \
-                            uint32_t* ogb, uint32_t* ogc, uint32_t* totals);                        \
+                            uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage);                    \
     void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base, \
-                            const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq); \
+                            const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles, \
+                            const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const DCtl* ctl); \
     void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq, \
-                      uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters, \
+                      uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, DCtl* ctl, \
                       unsigned long long* evals, ShadeHooks hooks, const Tuning& tun);              \
     void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile, \
-                                const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn);     \
+                                const uint32_t* tile_out_base, uint32_t max_slots, uint32_t* qn, uint32_t n_tiles, const uint32_t* tile_total, \
+                                const DCtl* ctl);                                                   \
+    void launch_batch_setup(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t* pgrp_tile, uint32_t* tgb, uint32_t* tgc); \
     void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool, \
                         float* out_color, float* out_alpha, float* out_background, float* out_normal); \
     void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n); \
@@ -110,13 +128,14 @@ struct KernelSet {
     decltype(&rayn_p0::launch_bin_scatter) bin_scatter;
     decltype(&rayn_p0::launch_shade) shade;
     decltype(&rayn_p0::launch_compact_scatter) compact_scatter;
+    decltype(&rayn_p0::launch_batch_setup) batch_setup;
     decltype(&rayn_p0::launch_resolve) resolve;
     decltype(&rayn_p0::launch_probe_dist) probe_dist;
     decltype(&rayn_p0::launch_probe_closest) probe_closest;
     decltype(&rayn_p0::launch_probe_occluded) probe_occluded;
     decltype(&rayn_p0::launch_probe_detmath) probe_detmath;
 };
-#define RAYN_KERNEL_SET(NS) KernelSet{&NS::launch_pack_tables, &NS::launch_raygen, &NS::launch_extend, &NS::launch_scan_tile, &NS::launch_tile_prefix, &NS::launch_bin_scatter, &NS::launch_shade, &NS::launch_compact_scatter, &NS::launch_resolve, &NS::launch_probe_dist, &NS::launch_probe_closest, &NS::launch_probe_occluded, &NS::launch_probe_detmath}
+#define RAYN_KERNEL_SET(NS) KernelSet{&NS::launch_pack_tables, &NS::launch_raygen, &NS::launch_extend, &NS::launch_scan_tile, &NS::launch_tile_prefix, &NS::launch_bin_scatter, &NS::launch_shade, &NS::launch_compact_scatter, &NS::launch_batch_setup, &NS::launch_resolve, &NS::launch_probe_dist, &NS::launch_probe_closest, &NS::launch_probe_occluded, &NS::launch_probe_detmath}
 inline KernelSet kernel_set(int fma_policy) {
     if (fma_policy) return RAYN_KERNEL_SET(rayn_p1);
     return RAYN_KERNEL_SET(rayn_p0);

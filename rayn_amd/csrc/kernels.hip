@@ -36,15 +36,27 @@ __global__ void __launch_bounds__(256) k_pack_tables(Tables tab, float4* __restr
     for (uint32_t c = 0; c < n2; c++) dst[8 + c] = tab.s2d[(c & 1) + s * 2 + spp * 2 * (2 + (c >> 1) + depth * (n2 / 2))]; // src/film.rs:580-587
 }
 
+// Per-batch bookkeeping derived from the tile list ON DEVICE (the host uploads all tile lists once per frame): the tile of
+// every 64-slot pool group and the tile's initial group range in the ray queue.  One block per tile.
+__global__ void __launch_bounds__(256) k_batch_setup(const DTile* __restrict__ tiles, uint32_t* __restrict__ pgrp_tile,
+                                                      uint32_t* __restrict__ tgb, uint32_t* __restrict__ tgc) {
+    const uint32_t k = blockIdx.x;
+    const DTile t = tiles[k];
+    const uint32_t g0 = t.pool_base >> 6, groups = (t.n_paths + 63u) >> 6;
+    if (threadIdx.x == 0) { tgb[k] = g0; tgc[k] = groups; }
+    for (uint32_t g = threadIdx.x; g < groups; g += 256) pgrp_tile[g0 + g] = k;
+}
+
 // ------------------------------------------------------------------------------------------------
 // a8: tile ray-gen loop, src/film.rs:456-529 (+ sample_uv :695-709, Camera::get_rays).
 // One thread per pool slot.  Pool order inside a tile: x outer, y inner, sample innermost.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raygen(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                  const DTile* __restrict__ tiles, const uint32_t* __restrict__ pgrp_tile,
-                                                 Pool pool, uint32_t* __restrict__ q, uint32_t n_pool) {
+                                                 Pool pool, uint32_t* __restrict__ q, uint32_t n_pool, DCtl* __restrict__ ctl) {
     const uint32_t P = blockIdx.x * blockDim.x + threadIdx.x;
     if (P >= n_pool) return;
+    if (P == 0) { ctl->q_groups = n_pool >> 6; ctl->q_valid = n_pool; ctl->head_extend = 0; } // n_pool is a multiple of 64
     const DScene& sc = *scp;
     const DTile tile = tiles[pgrp_tile[P >> 6]];
     const uint32_t p = P - tile.pool_base;
@@ -98,9 +110,11 @@ constexpr uint32_t ENDGAME_ENTRIES = 256 * 32 * 64; // about one ray per residen
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, uint32_t depth, const uint32_t* __restrict__ q,
-                                                 uint32_t n_entries, Pool pool, uint8_t* __restrict__ ent_obj,
-                                                 uint32_t* __restrict__ head, uint32_t REFILL_MIN, unsigned long long* __restrict__ evals_out) {
+                                                 DCtl* __restrict__ ctl, Pool pool, uint8_t* __restrict__ ent_obj,
+                                                 uint32_t REFILL_MIN, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
+    const uint32_t n_entries = ctl->q_groups << 6;
+    uint32_t* const head = &ctl->head_extend;
     const uint32_t lane = lane_id();
     const Thr th = make_thr(sc, depth);
     const uint32_t nh = sc.n_hitables;
@@ -209,9 +223,11 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
 // ------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp, uint32_t depth, uint32_t ks, const uint32_t* __restrict__ q,
-                                                  uint32_t n_entries, Pool pool, uint8_t* __restrict__ ent_obj,
-                                                  uint32_t* __restrict__ head, uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
+                                                  DCtl* __restrict__ ctl, Pool pool, uint8_t* __restrict__ ent_obj,
+                                                  uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
+    const uint32_t n_entries = ctl->q_groups << 6;
+    uint32_t* const head = &ctl->head_extend;
     const uint32_t lane = lane_id();
     const Thr th = make_thr(sc, depth);
     const uint32_t nh = sc.n_hitables, max_marches = sc.max_marches;
@@ -323,14 +339,17 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
 }
 
 // per-group object histogram of the extend results (input of the bin scan)
-__global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8_t* __restrict__ ent_obj, uint32_t n_entries,
+__global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8_t* __restrict__ ent_obj, const DCtl* __restrict__ ctl,
                                                      uint8_t* __restrict__ grp_cnt) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_entries) return;
-    const uint32_t obj = ent_obj[i], g = i >> 6, lane = lane_id();
-    for (uint32_t c = 0; c < nclass; c++) {
-        uint64_t m = __ballot(obj == c);
-        if (lane == c) grp_cnt[g * SCAN_NC_BIN + c] = (uint8_t)__popcll(m);
+    const uint32_t n_entries = ctl->q_groups << 6, lane = lane_id();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += gridDim.x * blockDim.x) { // whole waves: n_entries % 64 == 0
+        const uint32_t obj = ent_obj[i], g = i >> 6;
+        uint32_t mine = 0;
+        for (uint32_t c = 0; c < nclass; c++) {
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(obj == c));
+            if (lane == c) mine = cnt;
+        }
+        if (lane < nclass) grp_cnt[g * SCAN_NC_BIN + lane] = (uint8_t)mine; // one store of nclass bytes per group
     }
 }
 
@@ -369,7 +388,8 @@ RD uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave_tot, uint32_t* total)
 __global__ void __launch_bounds__(256) k_scan_tile(uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* __restrict__ grp_cnt,
                                                     const uint32_t* __restrict__ tile_grp_begin, const uint32_t* __restrict__ tile_grp_count,
                                                     uint32_t* __restrict__ grp_base, uint32_t* __restrict__ grp_tile,
-                                                    uint32_t* __restrict__ tile_total, uint32_t* __restrict__ tile_valid) {
+                                                    uint32_t* __restrict__ tile_total, uint32_t* __restrict__ tile_valid,
+                                                    uint32_t* __restrict__ tile_cls_cnt) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_run[SCAN_NC_BIN];
     __shared__ uint32_t s_off[SCAN_NC_BIN];
@@ -397,6 +417,7 @@ __global__ void __launch_bounds__(256) k_scan_tile(uint32_t nclass, uint32_t str
         for (uint32_t c = 0; c < nclass; c++) {
             s_off[c] = off;
             valid += s_run[c];
+            tile_cls_cnt[k * SCAN_NC_BIN + c] = s_run[c];
             off += (s_run[c] + pad - 1) / pad * pad;
         }
         tile_total[k] = off;
@@ -407,12 +428,13 @@ __global__ void __launch_bounds__(256) k_scan_tile(uint32_t nclass, uint32_t str
         for (uint32_t c = 0; c < nclass; c++) grp_base[(gb + gi) * stride + c] += s_off[c];
 }
 
-// prefix over the tiles of the batch: where each tile's (64-padded) output segment starts.
-// totals[0] = output groups, totals[1] = valid entries.
+// prefix over the tiles of the batch: where each tile's (64-padded) output segment starts.  The totals (output groups,
+// valid entries) go to the device control block - stage 0 = bin (binned queue size; resets the shadow job list),
+// stage 1 = repack (next ray queue size; resets the extend queue head) - together with the frame statistics.
 __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const uint32_t* __restrict__ tile_total,
                                                        const uint32_t* __restrict__ tile_valid, uint32_t* __restrict__ tile_out_base,
                                                        uint32_t* __restrict__ out_grp_begin, uint32_t* __restrict__ out_grp_count,
-                                                       uint32_t* __restrict__ totals) {
+                                                       DCtl* __restrict__ ctl, int stage) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_vsum[16];
     __shared__ uint32_t s_run, s_valid;
@@ -452,40 +474,77 @@ __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const ui
         if (threadIdx.x == 0) { s_run = run + tot; s_valid += vtot; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { totals[0] = s_run; totals[1] = s_valid; }
+    if (threadIdx.x == 0) {
+        if (stage == 0) {
+            ctl->entries_sum += (unsigned long long)ctl->q_groups << 6;
+            ctl->b_groups = s_run; ctl->b_valid = s_valid;
+            ctl->segments += s_valid; ctl->shaded_slots += (unsigned long long)s_run << 6;
+            ctl->job_count = 0; ctl->head_shadow = 0;
+        } else {
+            ctl->q_groups = s_run; ctl->q_valid = s_valid;
+            ctl->next_sum += (unsigned long long)s_run << 6;
+            ctl->head_extend = 0;
+        }
+    }
+}
+
+// INVALID padding of a tile's output segment, written by the scatter kernels themselves (no memset of the whole queue): every
+// class bin is padded to a multiple of 'pad' slots and the tile's segment to a multiple of 64.  One block per tile (strided).
+RD void write_tile_padding(uint32_t n_tiles, uint32_t nclass, uint32_t pad, const uint32_t* __restrict__ tile_cls_cnt,
+                           const uint32_t* __restrict__ tile_total, const uint32_t* __restrict__ tile_out_base, uint32_t* __restrict__ out) {
+    for (uint32_t k = blockIdx.x; k < n_tiles; k += gridDim.x) {
+        const uint32_t base = tile_out_base[k], total = tile_total[k];
+        if (pad > 1 && threadIdx.x < nclass) { // pad <= 4: at most 3 slots per class
+            uint32_t off = 0, cnt = 0;
+            for (uint32_t c = 0; c <= threadIdx.x; c++) {
+                off += (cnt + pad - 1) / pad * pad;
+                cnt = tile_cls_cnt[k * SCAN_NC_BIN + c];
+            }
+            for (uint32_t e = cnt; e < (cnt + pad - 1) / pad * pad; e++) out[base + off + e] = INVALID;
+        }
+        if (threadIdx.x >= 64 && threadIdx.x < 128) { // tail of the tile's segment
+            const uint32_t e = total + (threadIdx.x - 64);
+            if (e < ((total + 63u) & ~63u)) out[base + e] = INVALID;
+        }
+    }
 }
 
 // stable scatter of the queue into object bins (a14)
 __global__ void __launch_bounds__(256) k_bin_scatter(uint32_t nclass, const uint32_t* __restrict__ q, const uint8_t* __restrict__ ent_obj,
                                                       const uint32_t* __restrict__ grp_base, const uint32_t* __restrict__ grp_tile,
-                                                      const uint32_t* __restrict__ tile_out_base, uint32_t n_entries,
-                                                      uint32_t* __restrict__ bq) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_entries) return;
-    const uint32_t g = i >> 6;
-    const uint32_t obj = ent_obj[i];
-    uint32_t rank = 0;
-    for (uint32_t c = 0; c < nclass; c++) {
-        uint64_t m = __ballot(obj == c);
-        if (obj == c) rank = mbcnt(m);
+                                                      const uint32_t* __restrict__ tile_out_base, const DCtl* __restrict__ ctl,
+                                                      uint32_t* __restrict__ bq, uint32_t n_tiles, const uint32_t* __restrict__ tile_cls_cnt,
+                                                      const uint32_t* __restrict__ tile_total) {
+    write_tile_padding(n_tiles, nclass, 4, tile_cls_cnt, tile_total, tile_out_base, bq);
+    const uint32_t n_entries = ctl->q_groups << 6;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += gridDim.x * blockDim.x) {
+        const uint32_t g = i >> 6;
+        const uint32_t obj = ent_obj[i];
+        uint32_t rank = 0;
+        for (uint32_t c = 0; c < nclass; c++) {
+            uint64_t m = __ballot(obj == c);
+            if (obj == c) rank = mbcnt(m);
+        }
+        if (obj == OBJ_NONE) continue;
+        const uint32_t dst = tile_out_base[grp_tile[g]] + grp_base[g * SCAN_NC_BIN + obj] + rank;
+        bq[dst] = q[i];
     }
-    if (obj == OBJ_NONE) return;
-    const uint32_t dst = tile_out_base[grp_tile[g]] + grp_base[g * SCAN_NC_BIN + obj] + rank;
-    bq[dst] = q[i];
 }
 
 // stable compaction of the survivors of a shade pass into the next ray queue (a26)
 __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restrict__ bq, const uint8_t* __restrict__ alive,
                                                           const uint32_t* __restrict__ grp_base, const uint32_t* __restrict__ grp_tile,
-                                                          const uint32_t* __restrict__ tile_out_base, uint32_t n_slots,
-                                                          uint32_t* __restrict__ qn) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_slots) return;
-    const uint32_t g = j >> 6;
-    const bool a = alive[j] != 0;
-    const uint32_t rank = mbcnt(__ballot(a));
-    if (!a) return;
-    qn[tile_out_base[grp_tile[g]] + grp_base[g] + rank] = bq[j];
+                                                          const uint32_t* __restrict__ tile_out_base, const DCtl* __restrict__ ctl,
+                                                          uint32_t* __restrict__ qn, uint32_t n_tiles, const uint32_t* __restrict__ tile_total) {
+    write_tile_padding(n_tiles, 1, 1, nullptr, tile_total, tile_out_base, qn);
+    const uint32_t n_slots = ctl->b_groups << 6;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_slots; j += gridDim.x * blockDim.x) {
+        const uint32_t g = j >> 6;
+        const bool a = alive[j] != 0;
+        const uint32_t rank = mbcnt(__ballot(a));
+        if (!a) continue;
+        qn[tile_out_base[grp_tile[g]] + grp_base[g] + rank] = bq[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,15 +566,16 @@ constexpr uint32_t VOL_MEMO_LIGHTS = 7; // per-light volume terms memoised in LD
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
-                                                      uint32_t depth, const uint32_t* __restrict__ bq, uint32_t n_slots, Pool pool, Nee nee,
+                                                      uint32_t depth, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl, Pool pool, Nee nee,
                                                       uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt, uint32_t ablate,
                                                       unsigned long long* __restrict__ evals_out) {
     // 'ablate' is a TIMING-ONLY debug mask (RAYN_HIP_ABLATE; results are wrong when non-zero): 1 no normal
     // estimation, 2 no surface NEE, 4 no BSDF scatter, 8 no sphere occlusion tests, 16 no BSDF::f
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_slots) return; // multiple of 64
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
+    const uint32_t n_slots = ctl->b_groups << 6;
+    uint32_t evals = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_slots; j += gridDim.x * blockDim.x) { // whole waves: n_slots % 64 == 0
     const uint32_t P = bq[j];
     const bool valid = P != INVALID;
     const uint32_t spp = sc.spp, nl = sc.n_lights, VM = sc.vm;
@@ -560,7 +620,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     const size_t cap = nee.cap;
     const bool scene_has_sdf = sc.n_sdf > 0;
     bool is_alive = false;
-    uint32_t evals = 0, flags = 0;
+    uint32_t flags = 0;
     // shadow jobs live IN PLACE: vis[s][slot] = 2 marks "SDF march pending" and the segment is parked at
     // job_geo[2*(s*cap + slot)..]; k_shadow_list collects the pending (sample, slot) pairs.  (A compacted job list would need
     // one atomic per wave per sample on a single counter - that alone cost 0.5 s per frame.)
@@ -740,6 +800,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     alive[j] = is_alive ? 1 : 0;
     uint64_t m = __ballot(is_alive);
     if (lane == 0) bgrp_cnt[j >> 6] = (uint8_t)__popcll(m);
+    } // grid-stride loop
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
@@ -750,13 +811,15 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
 // densely in lane order - coalesced 256-byte stores, and consecutive list entries point at consecutive segments, which
 // keeps the shadow kernel's fetch contiguous.  List order is irrelevant to the result: it is written back by index.
 constexpr uint32_t SCAN_ITEMS = 16;
-__global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, uint32_t n_slots, uint32_t* __restrict__ job_count) {
+__global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, DCtl* __restrict__ ctl) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
+    const uint32_t n_slots = ctl->b_groups << 6;
     const uint32_t n_ids = ns * n_slots;
+    uint32_t* const job_count = &ctl->job_count;
     const size_t cap = nee.cap;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t block_first = blockIdx.x * (256 * SCAN_ITEMS);
+    for (uint32_t block_first = blockIdx.x * (256 * SCAN_ITEMS); block_first < n_ids; block_first += gridDim.x * (256 * SCAN_ITEMS)) {
     uint32_t refs[SCAN_ITEMS];
     uint32_t wave_total = 0; // wave-uniform
 #pragma unroll
@@ -788,15 +851,19 @@ __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, uint3
         if (refs[r] != INVALID) nee.job_ref[w + mbcnt(m)] = refs[r];
         w += (uint32_t)__popcll(m);
     }
+    __syncthreads(); // s_wave / s_base are reused by the next chunk
+    }
 }
 
 // TracedSDF::occluded (src/sdf.rs:25-57) for the pending shadow segments, persistent waves (see k_extend).
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, Nee nee, const uint32_t* __restrict__ job_count,
-                                                 uint32_t* __restrict__ head, uint32_t REFILL_MIN, unsigned long long* __restrict__ evals_out) {
+__global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, Nee nee, DCtl* __restrict__ ctl,
+                                                 uint32_t REFILL_MIN, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
-    const uint32_t n_jobs = *job_count, nh = sc.n_hitables;
+    const uint32_t n_jobs = ctl->job_count, nh = sc.n_hitables;
+    uint32_t* const head = &ctl->head_shadow;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
@@ -872,11 +939,13 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
 // Fast path of k_shadow for scenes with exactly one TracedSDF: uniform SDF parameters, and a
 // prefetched NEXT segment per lane (see k_extend1).
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, const uint32_t* __restrict__ job_count,
-                                                  uint32_t* __restrict__ head, uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
+__global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, DCtl* __restrict__ ctl,
+                                                  uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
-    const uint32_t n_jobs = *job_count, max_vis = sc.max_vis_marches;
+    const uint32_t n_jobs = ctl->job_count, max_vis = sc.max_vis_marches;
+    uint32_t* const head = &ctl->head_shadow;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
     const DHitable h = sc.h[ks];
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
@@ -955,13 +1024,13 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
-__global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__ scp, const uint32_t* __restrict__ bq, uint32_t n_slots,
+__global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__ scp, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl,
                                                        Pool pool, Nee nee) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_slots) return;
-    const uint32_t P = bq[j];
-    if (P == INVALID) return;
     const DScene& sc = *scp;
+    const uint32_t n_slots = ctl->b_groups << 6;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_slots; j += gridDim.x * blockDim.x) {
+    const uint32_t P = bq[j];
+    if (P == INVALID) continue;
     const uint32_t flags = nee.flags[j], nl = sc.n_lights, VM = sc.vm;
     const size_t cap = nee.cap;
     if (flags & 6u) {
@@ -995,6 +1064,7 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
         pool.col0[P].w = nee.nthr[j];
         *(float2*)(&pool.col1[P].x) = make_float2(nee.nthr[cap + j], nee.nthr[2 * cap + j]);
     }
+    } // grid-stride loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1228,61 +1298,74 @@ static inline dim3 grid_for(uint32_t n, uint32_t block) { return dim3((n + block
 void launch_pack_tables(hipStream_t s, Tables tab, float4* out, uint32_t spp, uint32_t depths, uint32_t n1, uint32_t n2) {
     hipLaunchKernelGGL(k_pack_tables, grid_for(spp * depths, 256), dim3(256), 0, s, tab, out, spp, depths, n1, n2);
 }
-void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
-                   Pool pool, uint32_t* q, uint32_t n_pool) {
-    hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool);
+// grid of a grid-stride kernel over at most max_items items (the host's upper bound of a device-resident count)
+static inline dim3 stride_grid(uint32_t max_items, uint32_t per_block, uint32_t cap_blocks) {
+    const uint32_t need = (max_items + per_block - 1) / per_block;
+    return dim3(std::max<uint32_t>(1u, std::min<uint32_t>(need, cap_blocks)));
 }
-void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t n_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, uint32_t* head, unsigned long long* evals, const Tuning& tun) {
-    (void)hipMemsetAsync(head, 0, 4, s);
-    const dim3 grid(std::min<uint32_t>(tun.persistent_blocks, (n_entries + 255) / 256));
+constexpr uint32_t STREAM_BLOCKS = 256 * 8; // light streaming kernels: 8 blocks of 256 threads per CU
+constexpr uint32_t SETUP_BLOCKS = 256 * 12; // k_shade_setup: 6 resident blocks per CU, two rounds
+
+void launch_batch_setup(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t* pgrp_tile, uint32_t* tgb, uint32_t* tgc) {
+    hipLaunchKernelGGL(k_batch_setup, dim3(n_tiles), dim3(256), 0, s, tiles, pgrp_tile, tgb, tgc);
+}
+void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile,
+                   Pool pool, uint32_t* q, uint32_t n_pool, DCtl* ctl) {
+    hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool, ctl);
+}
+void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t max_entries, Pool pool,
+                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun) {
+    const dim3 grid = stride_grid(max_entries, 256, tun.persistent_blocks);
     if (single_sdf >= 0 && tun.fast_path) {
-        if (count) hipLaunchKernelGGL(k_extend1<true>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, n_entries, pool, ent_obj, head, tun.prefetch_min_extend, evals);
-        else hipLaunchKernelGGL(k_extend1<false>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, n_entries, pool, ent_obj, head, tun.prefetch_min_extend, evals);
-    } else if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, tun.refill_min_extend, evals);
-    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, n_entries, pool, ent_obj, head, tun.refill_min_extend, evals);
-    hipLaunchKernelGGL(k_group_hist, grid_for(n_entries, 256), dim3(256), 0, s, nclass, ent_obj, n_entries, grp_cnt);
+        if (count) hipLaunchKernelGGL(k_extend1<true>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
+        else hipLaunchKernelGGL(k_extend1<false>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
+    } else if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
+    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
+    hipLaunchKernelGGL(k_group_hist, stride_grid(max_entries, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, ent_obj, ctl, grp_cnt);
 }
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
                       const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
-                      uint32_t* tile_valid) {
-    hipLaunchKernelGGL(k_scan_tile, dim3(n_tiles), dim3(256), 0, s, nclass, stride, pad, grp_cnt, tgb, tgc, grp_base, grp_tile, tile_total, tile_valid);
+                      uint32_t* tile_valid, uint32_t* tile_cls_cnt) {
+    hipLaunchKernelGGL(k_scan_tile, dim3(n_tiles), dim3(256), 0, s, nclass, stride, pad, grp_cnt, tgb, tgc, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt);
 }
 void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
-                        uint32_t* ogb, uint32_t* ogc, uint32_t* totals) {
-    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, s, n_tiles, tile_total, tile_valid, tile_out_base, ogb, ogc, totals);
+                        uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage) {
+    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, s, n_tiles, tile_total, tile_valid, tile_out_base, ogb, ogc, ctl, stage);
 }
 void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
-                        const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t n_entries, uint32_t* bq) {
-    hipLaunchKernelGGL(k_bin_scatter, grid_for(n_entries, 256), dim3(256), 0, s, nclass, q, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
+                        const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles,
+                        const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const DCtl* ctl) {
+    hipLaunchKernelGGL(k_bin_scatter, stride_grid(max_entries, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, q, ent_obj, grp_base, grp_tile, tile_out_base, ctl, bq,
+                       n_tiles, tile_cls_cnt, tile_total);
 }
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
-                  uint32_t n_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, uint32_t* counters,
+                  uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, DCtl* ctl,
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
-    (void)hipMemsetAsync(counters + 1, 0, 8, s); // [1] shadow job count, [2] shadow queue head
     hooks.before(0);
     const uint32_t shmem = ns > 4 ? VOL_MEMO_LIGHTS * 3 * 256 * 4 : 0; // ns > 4: the volume scatters (volume NEE samples exist)
-    if (count) hipLaunchKernelGGL(k_shade_setup<true>, grid_for(n_slots, 256), dim3(256), shmem, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
-    else hipLaunchKernelGGL(k_shade_setup<false>, grid_for(n_slots, 256), dim3(256), shmem, s, sc, tab, scramble, depth, bq, n_slots, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+    const dim3 sgrid = stride_grid(max_slots, 256, SETUP_BLOCKS);
+    if (count) hipLaunchKernelGGL(k_shade_setup<true>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+    else hipLaunchKernelGGL(k_shade_setup<false>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
     hooks.after(0);
     if (has_sdf) {
         hooks.before(1);
-        hipLaunchKernelGGL(k_shadow_list, grid_for(ns * n_slots, 256 * SCAN_ITEMS), dim3(256), 0, s, nee, ns, n_slots, counters + 1);
-        const dim3 grid(std::min<uint32_t>(tun.persistent_blocks, (ns * n_slots + 255) / 256));
+        hipLaunchKernelGGL(k_shadow_list, stride_grid(ns * max_slots, 256 * SCAN_ITEMS, STREAM_BLOCKS), dim3(256), 0, s, nee, ns, ctl);
+        const dim3 grid = stride_grid(ns * max_slots, 256, tun.persistent_blocks);
         if (single_sdf >= 0 && tun.fast_path) {
-            if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, counters + 1, counters + 2, tun.prefetch_min_shadow, evals + 2);
-            else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, counters + 1, counters + 2, tun.prefetch_min_shadow, evals + 2);
-        } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, tun.refill_min_shadow, evals + 2);
-        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, counters + 1, counters + 2, tun.refill_min_shadow, evals + 2);
+            if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
+            else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
+        } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
+        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
         hooks.after(1);
     }
     hooks.before(2);
-    hipLaunchKernelGGL(k_shade_finish, grid_for(n_slots, 256), dim3(256), 0, s, sc, bq, n_slots, pool, nee);
+    hipLaunchKernelGGL(k_shade_finish, stride_grid(max_slots, 256, STREAM_BLOCKS), dim3(256), 0, s, sc, bq, ctl, pool, nee);
     hooks.after(2);
 }
 void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
-                            const uint32_t* tile_out_base, uint32_t n_slots, uint32_t* qn) {
-    hipLaunchKernelGGL(k_compact_scatter, grid_for(n_slots, 256), dim3(256), 0, s, bq, alive, grp_base, grp_tile, tile_out_base, n_slots, qn);
+                            const uint32_t* tile_out_base, uint32_t max_slots, uint32_t* qn, uint32_t n_tiles, const uint32_t* tile_total,
+                            const DCtl* ctl) {
+    hipLaunchKernelGGL(k_compact_scatter, stride_grid(max_slots, 256, STREAM_BLOCKS), dim3(256), 0, s, bq, alive, grp_base, grp_tile, tile_out_base, ctl, qn, n_tiles, tile_total);
 }
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {

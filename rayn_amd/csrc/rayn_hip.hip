@@ -49,6 +49,8 @@ struct Worker {
     hipStream_t stream = nullptr;
     Arena arena;
     uint32_t* h_totals = nullptr;          // pinned
+    DCtl* h_ctl = nullptr;                 // pinned: the control block read back once per frame share
+    std::vector<DTile> h_tiles;            // staging of every batch's tile list (one upload per frame share)
     unsigned long long* d_evals = nullptr; // [4]
     hipEvent_t done = nullptr;
     std::vector<ProfRec> prof;
@@ -78,6 +80,7 @@ struct rayn_ctx {
     size_t two_worker_min_paths = (size_t)1 << 22;
     int n_workers = 2;
     Tuning tun;
+    std::vector<uint32_t> tile_subset; // rayn_hip_set_tile_subset: render only these tiles (sorted)
     int trace_tile = -1;             // diagnostics: dump the packet order of this tile (rayn_hip_set_trace_tile)
     std::vector<uint32_t> trace;     // records of 6 u32: depth, object, tile x, tile y, sample, valid
     int fma_policy = 0; // 0: mul_add unfused (reference default build), 1: fused
@@ -304,6 +307,8 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     const size_t BCAP = CAP + max_tiles * (SCAN_NC_BIN * 3 + 64);  // binned slots (x4 bin padding + tails)
     const size_t QG = QCAP / 64 + 1, BG = BCAP / 64 + 1;
     const size_t JOBCAP = (size_t)NS * BCAP;
+    size_t total_tiles = 0;
+    for (auto& b : batches) total_tiles += b.size();
     if (JOBCAP >= ((size_t)1 << 32) || BCAP >= ((size_t)1 << 31)) return wfail(w, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
     size_t need = 0;
     auto acc = [&](size_t n, size_t sz) { need += (n * sz + 255) & ~(size_t)255; };
@@ -312,9 +317,9 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     acc(QCAP, 4); acc(QCAP, 4); acc(BCAP, 4); acc(QCAP, 1); acc(BCAP, 1);                          // q, qn, bq, ent_obj, alive
     acc(QG * SCAN_NC_BIN, 1); acc(QG * SCAN_NC_BIN, 4); acc(QG, 4);                                // grp_cnt, grp_base, grp_tile
     acc(BG, 1); acc(BG, 4); acc(BG, 4);                                                            // bgrp_*
-    acc(max_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                           // tiles, pgrp_tile
+    acc(total_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                         // tiles of every batch, pgrp_tile
     for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
-    acc(2, 4); acc(8, 4);
+    acc(max_tiles * SCAN_NC_BIN, 4); acc(1, sizeof(DCtl));                                         // tile_cls_cnt, control block
     acc(NS * 3 * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);
     acc(JOBCAP, 4); acc(2 * JOBCAP, 16);
     if (need > w->arena.cap) {
@@ -333,12 +338,12 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     uint8_t* ent_obj = A.take<uint8_t>(QCAP); uint8_t* alive = A.take<uint8_t>(BCAP);
     uint8_t* grp_cnt = A.take<uint8_t>(QG * SCAN_NC_BIN); uint32_t* grp_base = A.take<uint32_t>(QG * SCAN_NC_BIN); uint32_t* grp_tile = A.take<uint32_t>(QG);
     uint8_t* bgrp_cnt = A.take<uint8_t>(BG); uint32_t* bgrp_base = A.take<uint32_t>(BG); uint32_t* bgrp_tile = A.take<uint32_t>(BG);
-    DTile* d_tiles = A.take<DTile>(max_tiles); uint32_t* pgrp_tile = A.take<uint32_t>(CAP / 64 + 1);
+    DTile* d_all_tiles = A.take<DTile>(total_tiles); uint32_t* pgrp_tile = A.take<uint32_t>(CAP / 64 + 1);
     uint32_t* tgbA = A.take<uint32_t>(max_tiles); uint32_t* tgcA = A.take<uint32_t>(max_tiles);
     uint32_t* tgbB = A.take<uint32_t>(max_tiles); uint32_t* tgcB = A.take<uint32_t>(max_tiles);
     uint32_t* tile_total = A.take<uint32_t>(max_tiles); uint32_t* tile_valid = A.take<uint32_t>(max_tiles); uint32_t* tile_out_base = A.take<uint32_t>(max_tiles);
-    uint32_t* d_totals = A.take<uint32_t>(2);
-    uint32_t* d_counters = A.take<uint32_t>(8);
+    uint32_t* tile_cls_cnt = A.take<uint32_t>(max_tiles * SCAN_NC_BIN);
+    DCtl* d_ctl = A.take<DCtl>(1);
     Nee nee;
     nee.cap = BCAP; nee.jobcap = JOBCAP;
     nee.x = A.take<float>(NS * 3 * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
@@ -346,54 +351,53 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float4>(2 * JOBCAP);
     if (A.off > A.cap) return wfail(w, RAYN_ERR_OOM, "internal: arena under-sized");
 
+    // The whole share is ENQUEUED without a single host<->device round trip: queue sizes live in d_ctl, the tile lists of all
+    // batches go up in one copy (the staging vector belongs to the worker and outlives the copy), kernels size themselves.
+    w->h_tiles.clear();
+    for (auto& batch : batches) for (auto& bt : batch) w->h_tiles.push_back(bt.d);
+    WCHK(hipMemcpyAsync(d_all_tiles, w->h_tiles.data(), total_tiles * sizeof(DTile), hipMemcpyHostToDevice, stream));
+    WCHK(hipMemsetAsync(d_ctl, 0, sizeof(DCtl), stream));
     WCHK(hipMemsetAsync(w->d_evals, 0, 32, stream));
     const bool count = F.count, prof = F.profiling;
     const Tables& tab = F.tab;
-    std::vector<DTile> h_tiles; std::vector<uint32_t> h_pgrp, h_tgb, h_tgc;
+    const uint32_t last_depth = F.p->max_bounces; // a path that reaches depth == max_bounces terminates there (src/integrator.rs:171)
+    size_t tile_cursor = 0;
     for (auto& batch : batches) {
         const uint32_t nt = (uint32_t)batch.size();
-        h_tiles.resize(nt); h_tgb.resize(nt); h_tgc.resize(nt);
+        const DTile* d_tiles = d_all_tiles + tile_cursor;
+        tile_cursor += nt;
         size_t n_pool = 0;
-        h_pgrp.clear();
         for (uint32_t i = 0; i < nt; i++) {
-            h_tiles[i] = batch[i].d;
-            uint32_t groups = (batch[i].d.n_paths + 63) / 64;
-            h_tgb[i] = batch[i].d.pool_base / 64; h_tgc[i] = groups;
-            h_pgrp.insert(h_pgrp.end(), groups, i);
-            n_pool += (size_t)groups * 64;
+            n_pool += (size_t)((batch[i].d.n_paths + 63) / 64) * 64;
             w->stats.paths += batch[i].d.n_paths;
         }
         w->stats.tiles += nt; w->stats.batches++;
-        // the staging vectors are reused by the next batch: finish these copies before going on
-        WCHK(hipMemcpyAsync(d_tiles, h_tiles.data(), nt * sizeof(DTile), hipMemcpyHostToDevice, stream));
-        WCHK(hipMemcpyAsync(pgrp_tile, h_pgrp.data(), h_pgrp.size() * 4, hipMemcpyHostToDevice, stream));
-        WCHK(hipMemcpyAsync(tgbA, h_tgb.data(), nt * 4, hipMemcpyHostToDevice, stream));
-        WCHK(hipMemcpyAsync(tgcA, h_tgc.data(), nt * 4, hipMemcpyHostToDevice, stream));
-        WCHK(hipStreamSynchronize(stream));
-
-        { Timed t(w, prof, PC_RAYGEN); K.raygen(stream, ctx->d_scene, tab, F.d_scr, d_tiles, pgrp_tile, pool, q, (uint32_t)n_pool); }
-        uint32_t n_entries = (uint32_t)n_pool;
+        // upper bounds of the device-resident queue sizes of this batch (grids are sized for them)
+        const uint32_t max_entries = (uint32_t)n_pool, max_slots = (uint32_t)std::min<size_t>(BCAP, n_pool + (size_t)nt * (SCAN_NC_BIN * 3 + 64));
+        {
+            Timed t(w, prof, PC_RAYGEN);
+            K.batch_setup(stream, d_tiles, nt, pgrp_tile, tgbA, tgcA);
+            K.raygen(stream, ctx->d_scene, tab, F.d_scr, d_tiles, pgrp_tile, pool, q, (uint32_t)n_pool, d_ctl);
+        }
         uint32_t* qcur = q; uint32_t* qnext = qn;
-        for (uint32_t depth = 0; n_entries > 0; depth++) {
-            { Timed t(w, prof, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, n_entries, pool, ent_obj, grp_cnt, hs.n_hitables, F.single_sdf, d_counters, w->d_evals, ctx->tun); }
+        for (uint32_t depth = 0; depth <= last_depth; depth++) {
+            // deep configurations: look at the queue size now and then, so that a batch whose paths all died early (roulette)
+            // does not enqueue dozens of empty depths; <= 8 bounces never synchronise
+            if (depth >= 8 && (depth & 3u) == 0) {
+                WCHK(hipMemcpyAsync(w->h_totals, &d_ctl->q_groups, 8, hipMemcpyDeviceToHost, stream));
+                WCHK(hipStreamSynchronize(stream));
+                if (w->h_totals[1] == 0) break;
+            }
+            { Timed t(w, prof, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, max_entries, pool, ent_obj, grp_cnt, hs.n_hitables, F.single_sdf, d_ctl, w->d_evals, ctx->tun); }
             w->stats.launches_extend++;
             {
                 Timed t(w, prof, PC_BIN);
-                K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_totals);
+                K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0);
+                K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, max_entries, bq, nt, tile_cls_cnt, tile_total, d_ctl);
             }
-            WCHK(hipMemcpyAsync(w->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
-            WCHK(hipStreamSynchronize(stream));
-            const uint32_t n_slots = w->h_totals[0] * 64, n_hits = w->h_totals[1];
-            w->stats.segments += n_hits;
-            if (n_hits == 0) break;
-            if (n_slots > BCAP) return wfail(w, RAYN_ERR_OOM, "internal: binned queue overflow");
-            {
-                Timed t(w, prof, PC_BIN);
-                WCHK(hipMemsetAsync(bq, 0xFF, (size_t)n_slots * 4, stream));
-                K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, n_entries, bq);
-            }
-            if (ctx->trace_tile >= 0) { // diagnostics only: packet order of one tile, in HitStore::process_hits order
+            if (ctx->trace_tile >= 0) { // diagnostics only (synchronises): packet order of one tile, in HitStore::process_hits order
+                WCHK(hipStreamSynchronize(stream));
                 for (uint32_t i = 0; i < nt; i++) {
                     if ((int)batch[i].tile_index != ctx->trace_tile) continue;
                     const DTile& td = batch[i].d;
@@ -420,8 +424,6 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
                     }
                 }
             }
-            // group_hist reads 1 B/entry; scatter reads q (4) + ent_obj (1), writes bq (4); memset writes bq (4); scans ~17 B/group
-            w->stats.queue_bytes_bin += (uint64_t)n_entries * (1 + 4 + 1) + (uint64_t)n_slots * (4 + 4) + (uint64_t)(n_entries / 64) * 85;
             {
                 static const int cls[3] = {PC_SHADE, PC_SHADOW, PC_FINISH};
                 struct HookState { Worker* w; bool on; Timed* cur; } hst{w, prof, nullptr};
@@ -429,35 +431,32 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
                 hooks.user = &hst;
                 hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->w, h->on, cls[i]); };
                 hooks.after_fn = [](void* u, int) { HookState* h = (HookState*)u; delete h->cur; h->cur = nullptr; };
-                K.shade(stream, count, ctx->d_scene, tab, F.d_scr, depth, bq, n_slots, pool, nee, NS, hs.n_sdf > 0, F.single_sdf, alive, bgrp_cnt, d_counters, w->d_evals, hooks, ctx->tun);
+                K.shade(stream, count, ctx->d_scene, tab, F.d_scr, depth, bq, max_slots, pool, nee, NS, hs.n_sdf > 0, F.single_sdf, alive, bgrp_cnt, d_ctl, w->d_evals, hooks, ctx->tun);
             }
             w->stats.launches_shade++;
-            w->stats.shaded_slots += n_slots;
+            if (depth == last_depth) break; // nothing survives the last depth: no repack
             {
                 Timed t(w, prof, PC_COMPACT);
-                K.scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_totals);
+                K.scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid, tile_cls_cnt);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_ctl, 1);
+                K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, max_slots, qnext, nt, tile_total, d_ctl);
             }
-            WCHK(hipMemcpyAsync(w->h_totals, d_totals, 8, hipMemcpyDeviceToHost, stream));
-            WCHK(hipStreamSynchronize(stream));
-            const uint32_t n_next = w->h_totals[0] * 64, n_alive = w->h_totals[1];
-            if (n_alive == 0) break;
-            if (n_next > QCAP) return wfail(w, RAYN_ERR_OOM, "internal: ray queue overflow");
-            {
-                Timed t(w, prof, PC_COMPACT);
-                WCHK(hipMemsetAsync(qnext, 0xFF, (size_t)n_next * 4, stream));
-                K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, n_slots, qnext);
-            }
-            // compact_scatter reads bq (4) + alive (1), writes q' (4); memset writes q' (4); scans ~9 B/group
-            w->stats.queue_bytes_compact += (uint64_t)n_slots * (4 + 1) + (uint64_t)n_next * (4 + 4) + (uint64_t)(n_slots / 64) * 9;
             std::swap(qcur, qnext);
-            n_entries = n_next;
         }
         { Timed t(w, prof, PC_RESOLVE); K.resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, F.d_color, F.d_alpha, F.d_bg, F.d_normal); }
     }
+    WCHK(hipMemcpyAsync(w->h_ctl, d_ctl, sizeof(DCtl), hipMemcpyDeviceToHost, stream));
     WCHK(hipEventRecord(w->done, stream));
-    WCHK(hipStreamSynchronize(stream));
+    WCHK(hipStreamSynchronize(stream)); // the only wait of the share
     WCHK(hipGetLastError());
+    {
+        const DCtl& c = *w->h_ctl;
+        w->stats.segments = c.segments; w->stats.shaded_slots = c.shaded_slots; w->stats.shadow_jobs = c.shadow_jobs;
+        // algorithmic HBM bytes of the queue stages: bin = hist 1 B/entry + scatter q 4 + ent_obj 1 per entry, bq 4 per slot,
+        // ~85 B of scan bookkeeping per group; repack = bq 4 + alive 1 per slot, q' 4 per survivor slot, ~9 B per group
+        w->stats.queue_bytes_bin = c.entries_sum * 6 + c.shaded_slots * 4 + (c.entries_sum / 64) * 85;
+        w->stats.queue_bytes_compact = c.shaded_slots * 5 + c.next_sum * 4 + (c.shaded_slots / 64) * 9;
+    }
     if (count) WCHK(hipMemcpy(w->evals, w->d_evals, 24, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -479,10 +478,12 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
 
     // ---- plan: owned tiles, dealt alternately to the workers
     std::vector<TileRect> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
+    if (!ctx->tile_subset.empty() && ctx->tile_subset.back() >= tiles.size()) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile subset index beyond the frame's tile count");
     std::vector<BatchTile> owned;
     size_t owned_paths = 0;
     for (uint32_t k = 0; k < tiles.size(); k++) {
-        if ((k + k / step) % step != p->tile_first) continue; // owner of tile k: rotates by one every 'step' tiles (rayn_hip.h)
+        if (!ctx->tile_subset.empty()) { if (!std::binary_search(ctx->tile_subset.begin(), ctx->tile_subset.end(), k)) continue; }
+        else if ((k + k / step) % step != p->tile_first) continue; // owner of tile k: rotates by one every 'step' tiles (rayn_hip.h)
         const TileRect& t = tiles[k];
         uint32_t ew = t.x1 - t.x0, eh = t.y1 - t.y0;
         if (!ew || !eh) continue;
@@ -554,6 +555,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         ctx->stats.tiles += w.stats.tiles; ctx->stats.batches += w.stats.batches;
         ctx->stats.launches_extend += w.stats.launches_extend; ctx->stats.launches_shade += w.stats.launches_shade;
         ctx->stats.queue_bytes_bin += w.stats.queue_bytes_bin; ctx->stats.queue_bytes_compact += w.stats.queue_bytes_compact;
+        ctx->stats.shadow_jobs += w.stats.shadow_jobs;
         for (int k = 0; k < 3; k++) ctx->evals[k] += w.evals[k];
     }
     HIPCHK(hipEventRecord(ctx->ev_b, stream));
@@ -583,7 +585,7 @@ int rayn_hip_create(int device, rayn_ctx** out) {
               hipEventCreate(&ctx->ev_b) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (Worker& w : ctx->workers)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess && hipMalloc((void**)&w.d_evals, 32) == hipSuccess &&
-             hipHostMalloc((void**)&w.h_totals, 16) == hipSuccess && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
+             hipHostMalloc((void**)&w.h_totals, 16) == hipSuccess && hipHostMalloc((void**)&w.h_ctl, sizeof(DCtl)) == hipSuccess && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { rayn_hip_destroy(ctx); return RAYN_ERR_HIP; }
     if (const char* e = getenv("RAYN_HIP_WORKERS")) ctx->n_workers = atoi(e);
     if (const char* e = getenv("RAYN_HIP_BATCH_PATHS")) { long long v = atoll(e); if (v >= 4096) ctx->batch_paths = (size_t)v; }
@@ -609,6 +611,7 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
         if (w.arena.base) (void)hipFree(w.arena.base);
         if (w.d_evals) (void)hipFree(w.d_evals);
         if (w.h_totals) (void)hipHostFree(w.h_totals);
+        if (w.h_ctl) (void)hipHostFree(w.h_ctl);
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
@@ -765,6 +768,14 @@ int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths) {
     if (!ctx || n_workers < 1 || n_workers > MAX_WORKERS) return RAYN_ERR_INVALID_ARG;
     ctx->n_workers = n_workers;
     ctx->two_worker_min_paths = (size_t)min_paths;
+    return RAYN_OK;
+}
+int rayn_hip_set_tile_subset(rayn_ctx* ctx, const uint32_t* tiles, uint32_t n) {
+    if (!ctx || (n && !tiles)) return RAYN_ERR_INVALID_ARG;
+    std::vector<uint32_t> v(tiles, tiles + n);
+    std::sort(v.begin(), v.end());
+    if (std::adjacent_find(v.begin(), v.end()) != v.end()) return fail(ctx, RAYN_ERR_INVALID_ARG, "duplicate tile index in the subset");
+    ctx->tile_subset.swap(v);
     return RAYN_OK;
 }
 int rayn_hip_set_trace_tile(rayn_ctx* ctx, int tile_index) {

@@ -74,6 +74,11 @@ class Context:
     def set_workers(self, n_workers, min_paths=1 << 22):
         self._chk(self._L.rayn_hip_set_workers(self.h, int(n_workers), int(min_paths)))
 
+    def set_tile_subset(self, tiles=None):
+        """Render only these tiles (reference tile order) until cleared with None / []."""
+        arr = np.ascontiguousarray([] if tiles is None else tiles, dtype=np.uint32)
+        self._chk(self._L.rayn_hip_set_tile_subset(self.h, arr.ctypes.data_as(C.POINTER(C.c_uint32)), len(arr)))
+
     def set_trace_tile(self, tile_index):
         self._chk(self._L.rayn_hip_set_trace_tile(self.h, int(tile_index)))
 

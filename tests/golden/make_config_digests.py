@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Oracle digests of WHOLE 16x16 tiles at the real BASELINE configurations.
+
+Packet grouping is per tile (src/hitable.rs:94-134, src/film.rs:456-529), so a 16x16 tile at 1024 / 4096 spp is a
+different computation from the 4x4-tile cases of FILM_CASES.  This script runs the CPU oracle on >= 8 spread tiles of
+
+    c3: 1920x1080, 1024 spp,  8 bounces, MandelBox + homogeneous volume   (the bench default)
+    c4: 3840x2160, 1024 spp, 12 bounces, MandelBox
+    c5: 7680x4320, 4096 spp, 16 bounces, MandelBox, moving camera + moving fractal (time-sampled motion blur)
+
+at FULL resolution and tile size, and writes per tile: the path / segment / packet / SDF-evaluation counts and one
+SHA-256 per film channel over the tile's float32 pixels (film row order, NaNs canonicalised to 0x7FC00000).
+tests/test_config_digests.py renders exactly these tiles on the GPU and compares.
+
+Tile choice is deterministic: a 4-spp probe of ~200 spread tiles ranks them by segment count; the script takes the
+most and the least expensive tile (fractal-heavy / sky), the last tile of a column (half height at 1080 rows), the
+first tile, and evenly spaced quantiles of the ranking of the tiles that see more than sky.
+
+    python tests/golden/make_config_digests.py [c3 c4 c5] [--tiles 12] [--jobs N]      (writes config_digests.json)
+
+About 15 core-minutes for c3, 5 for c4, 40 for c5 (one tile runs serially on one thread, like the reference).
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CONFIGS = {
+    # name: (scene, W, H, samples (= spp / 4), bounces)
+    "c3": ("s2", 1920, 1080, 256, 8),
+    "c4": ("s1", 3840, 2160, 256, 12),
+    "c5": ("s3", 7680, 4320, 1024, 16),
+}
+CHANNELS = ("color", "alpha", "background", "normal")
+
+
+def world_and_params(name, samples=None):
+    """The scene + frame parameters of a config (shared with the GPU test)."""
+    from rayn_amd import params as P
+    from rayn_amd import setup as S
+    scene, W, H, smp, bounces = CONFIGS[name]
+    # s3 = config 5: moving camera (reference-supported closure) + moving fractal (TracedSDF transform_seq extension)
+    cam, world = {"s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3}[scene]((W, H))
+    p = P.frame_params(W, H, smp if samples is None else samples, bounces)
+    return world.to_desc(cam), p
+
+
+def tile_rect(p, k):
+    ny = (p.height + p.height % p.tile_h) // p.tile_h
+    tx, ty = k // ny, k % ny
+    return tx * p.tile_w, ty * p.tile_h, min(tx * p.tile_w + p.tile_w, p.width), min(ty * p.tile_h + p.tile_h, p.height)
+
+
+def tile_digests(film, p, k):
+    """SHA-256 per channel over the tile's pixels (rows y0..y1, columns x0..x1 of the bottom-up film)."""
+    x0, y0, x1, y1 = tile_rect(p, k)
+    out = {}
+    for ch in CHANNELS:
+        a = np.ascontiguousarray(film[ch][y0:y1, x0:x1], np.float32).copy()
+        bits = a.view(np.uint32)
+        bits[np.isnan(a)] = 0x7FC00000
+        out[ch] = hashlib.sha256(bits.tobytes()).hexdigest()
+    return out
+
+
+def choose_tiles(name, n_pick, jobs, O):
+    wd, p = world_and_params(name, samples=1)
+    tabs = O.build_tables(4, p.max_bounces, p.volume_marches, p.frame, p.width, p.height)
+    nx = (p.width + p.width % p.tile_w) // p.tile_w
+    ny = (p.height + p.height % p.tile_h) // p.tile_h
+    n_tiles = nx * ny
+    probe = sorted(set(int(v) for v in np.linspace(0, n_tiles - 1, 200)))
+
+    def cost(k):
+        _, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[k])
+        return ctr.segments, ctr.paths
+
+    with ThreadPoolExecutor(jobs) as ex:
+        res = list(ex.map(cost, probe))
+    seg = [r[0] for r in res]
+    ranked = [k for _, k in sorted(zip(seg, probe))]
+    busy = [k for (s_, n_), k in sorted(zip(res, probe)) if s_ > n_]  # tiles that see more than sky (some path goes beyond depth 0)
+    picks = [ranked[-1], ranked[0], 0, (nx // 3) * ny + ny - 1]  # fractal-heavy, sky, first tile, last (half-height at H = 1080) tile of a column
+    for q in np.linspace(0.0, 0.97, max(n_pick - len(picks), 0)):  # the rest: evenly spaced quantiles of the non-sky ranking
+        picks.append(busy[int(q * (len(busy) - 1))] if busy else ranked[int(q * (len(ranked) - 1))])
+    out = []
+    for k in picks:
+        if k not in out:
+            out.append(k)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", default=["c3", "c4", "c5"])
+    ap.add_argument("--tiles", type=int, default=12)
+    ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--out", default=os.path.join(HERE, "config_digests.json"))
+    args = ap.parse_args()
+    from oracle import oracle_py as O
+    O.build()
+    result = json.load(open(args.out)) if os.path.exists(args.out) else {}
+    for name in args.configs:
+        t0 = time.time()
+        tiles = choose_tiles(name, args.tiles, args.jobs, O)
+        wd, p = world_and_params(name)
+        tabs = O.build_tables(4 * p.samples, p.max_bounces, p.volume_marches, p.frame, p.width, p.height)
+
+        def run(k):
+            film, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[k])
+            x0, y0, x1, y1 = tile_rect(p, k)
+            return {"tile": k, "rect": [x0, y0, x1, y1], "paths": ctr.paths, "segments": ctr.segments, "packets": ctr.packets,
+                    "dist_evals": ctr.dist_evals, "alpha_mean": float(film["alpha"][y0:y1, x0:x1].mean()), "sha256": tile_digests(film, p, k)}
+
+        with ThreadPoolExecutor(min(args.jobs, 4 if name == "c5" else args.jobs)) as ex:  # c5: 1.3 GB of film per oracle call
+            recs = list(ex.map(run, tiles))
+        scene, W, H, smp, bounces = CONFIGS[name]
+        result[name] = {"scene": scene, "width": W, "height": H, "samples": smp, "spp": 4 * smp, "max_bounces": bounces,
+                        "volume_marches": p.volume_marches, "frame": p.frame, "tile": [p.tile_w, p.tile_h], "tiles": recs,
+                        "oracle": "oracle/rayn_oracle.cpp, unfused mul_add (librayn_oracle.so)", "seconds": round(time.time() - t0, 1)}
+        json.dump(result, open(args.out, "w"), indent=1)
+        print(name, "done in", round(time.time() - t0, 1), "s:", [(r["tile"], r["segments"]) for r in recs], flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -474,13 +474,18 @@ def test_full_size_config2(gpu_ctx, oracle):
 
 def test_full_size_config3(gpu_ctx):
     """BASELINE configs[2] (the bench default) at FULL size: 1920x1080, 1024 spp, 8 bounces, volume = 2.12 G paths in 16
-    tile batches.  The CPU oracle needs minutes per 16x16 tile here, so the full-size checks are size-independent
-    properties: path conservation, finite film, and partition independence - one rank's 1/8 share of the tiles
-    (different batching, one worker) must reproduce the full frame's pixels bit for bit.  Bit parity with the oracle in
-    this regime (1024 spp, 8 bounces, volume) is covered at small size by FILM_CASES."""
+    tile batches.  Oracle parity: the whole 16x16 tiles of tests/golden/config_digests.json (CPU-oracle SHA-256 per tile
+    and channel, incl. fractal-heavy, sky and half-height tiles) are hashed out of the full frame and must match.  Plus the
+    size-independent properties: path conservation, finite film, and partition independence - one rank's 1/8 share of the
+    tiles (different batching, one worker) must reproduce the full frame's pixels bit for bit."""
+    import json
+    import os
+    import sys
     import torch
     import rayn_amd
     from rayn_amd.distributed import owned_pixels
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_config_digests as G
     W, H = 1920, 1080
     wd, p = case("s2", W, H, 256, 8)
     tabs = rayn_amd.build_tables(1024, 8, p.volume_marches, p.frame, W, H)
@@ -495,6 +500,11 @@ def test_full_size_config3(gpu_ctx):
     for ch in ("color", "background", "normal", "alpha"):
         assert bool(torch.isfinite(film[ch]).all()), ch
     assert float(film["alpha"].min()) >= 0.0 and float(film["alpha"].max()) <= 1.0
+    host = {"color": film["color"].cpu().numpy().reshape(H, W, 3), "alpha": film["alpha"].cpu().numpy().reshape(H, W),
+            "background": film["background"].cpu().numpy().reshape(H, W, 3), "normal": film["normal"].cpu().numpy().reshape(H, W, 3)}
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")))["c3"]
+    for t in cfg["tiles"]:
+        assert G.tile_digests(host, p, t["tile"]) == t["sha256"], t["tile"]
     wd2, p8 = case("s2", W, H, 256, 8, tile_first=3, tile_step=8)
     share = rayn_amd.film.alloc_device_film(W, H, "cuda:0")
     gpu_ctx.render_device(p8, d_tabs, share)
