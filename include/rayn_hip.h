@@ -183,8 +183,18 @@ typedef struct {
 
 typedef struct rayn_ctx rayn_ctx;
 
-/* Film::new (src/film.rs:184-203) + device selection.  One ctx per process/GPU. */
+/* Film::new (src/film.rs:184-203) + device selection: one ctx = one GPU ... */
 int rayn_hip_create(int device, rayn_ctx** out);
+/* ... or several ("rayn_hip_create(device_ids[], n)", the call being internally multi-GPU): one
+ * context over n_devices GPUs of this process, replacing rayon's tile tasks (src/film.rs:630-691) with one renderer per GPU.
+ * Every other entry point takes it like a single-device ctx; ALL device pointers passed to rayn_hip_render_frame_device
+ * then live on devices[0].  Per frame the tiles of the call's share are dealt to the devices in rotation (the j-th owned
+ * tile goes to device (j + j / n) % n), scene and tables are replicated, every device renders its tiles with its own
+ * streams, and each device other than devices[0] sends the pixels of its tiles to devices[0] with ONE peer copy over xGMI
+ * (hipMemcpyPeerAsync of 10 floats per pixel) - the only data that crosses devices.  A device id may repeat (the entries
+ * then share that GPU; used by the single-GPU tests).  rayn_hip_set_trace_tile is not supported on a multi-device ctx. */
+int rayn_hip_create_multi(const int* devices, int n_devices, rayn_ctx** out);
+int rayn_hip_device_count(const rayn_ctx* ctx); /* entries of the context (1 for rayn_hip_create) */
 void rayn_hip_destroy(rayn_ctx* ctx);
 const char* rayn_hip_last_error(const rayn_ctx* ctx);
 

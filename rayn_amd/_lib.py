@@ -7,11 +7,12 @@ import subprocess
 from . import _abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "librayn_hip.so")
+# RAYN_HIP_LIB: an alternative build of the same library (timing experiments, e.g. tools/ubench variants); default = the in-tree one
+LIB_PATH = os.environ.get("RAYN_HIP_LIB") or os.path.join(_CSRC, "librayn_hip.so")
 
 # every symbol include/rayn_hip.h declares
 EXPORTS = [
-    "rayn_hip_create", "rayn_hip_destroy", "rayn_hip_last_error", "rayn_hip_upload_world", "rayn_hip_render_frame",
+    "rayn_hip_create", "rayn_hip_create_multi", "rayn_hip_device_count", "rayn_hip_destroy", "rayn_hip_last_error", "rayn_hip_upload_world", "rayn_hip_render_frame",
     "rayn_hip_render_frame_device", "rayn_hip_get_stats", "rayn_sets_1d", "rayn_sets_2d", "rayn_build_rd_tables",
     "rayn_build_scramble", "rayn_build_fis_table", "rayn_build_fis_table_ex", "rayn_tile_count", "rayn_hip_set_profiling", "rayn_hip_get_eval_counts",
     "rayn_hip_set_batch_paths", "rayn_hip_set_workers", "rayn_hip_set_tile_subset", "rayn_hip_set_trace_tile", "rayn_hip_get_trace", "rayn_hip_fma_policy", "rayn_hip_set_fma_policy", "rayn_hip_sizeof", "rayn_hip_probe_sdf_dist",
@@ -49,6 +50,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
         L.rayn_hip_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rayn_hip_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.rayn_hip_device_count.argtypes = [vp]
         L.rayn_hip_destroy.argtypes = [vp]
         L.rayn_hip_destroy.restype = None
         L.rayn_hip_last_error.argtypes = [vp]

@@ -15,6 +15,14 @@
 #define RAYN_KNS rayn_p0
 #endif
 
+#ifdef RAYN_ABLATE_DETMATH /* TIMING EXPERIMENT ONLY (results are wrong): hardware approximations instead of the pinned f64-evaluated functions */
+#define dm_expf(x) __expf(x)
+#define dm_powf(x, y) __powf(x, y)
+#define dm_sincosf(x, s, c) __sincosf(x, s, c)
+#define dm_atan2f(y, x) atan2f(y, x)
+#define dm_tanf(x) __tanf(x)
+#endif
+
 namespace RAYN_KNS {
 using namespace rayn;
 
@@ -240,6 +248,11 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
 #ifndef RAYN_FOLD_BRANCHFREE
 #define RAYN_FOLD_BRANCHFREE 0
 #endif
+/* When fewer than this many lanes of the wave fold in an iteration, the block runs on all 64 lanes with a select instead of
+ * under the folding lanes' exec mask (0 = always exec-masked).  Same values either way: non-folding lanes multiply by 1.0. */
+#ifndef RAYN_FOLD_DENSE_BELOW
+#define RAYN_FOLD_DENSE_BELOW 0
+#endif
 #ifdef RAYN_COUNT_FOLDS /* experiment: the instrumented kernels count sphere-fold block entries (per active lane) instead of evaluations */
 #define RAYN_FOLD_COUNT_HOOK if (COUNT && fold) evals++;
 #else
@@ -267,14 +280,23 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
                 const float m = fold ? q : 1.0f;                                              \
                 p.x *= m; p.y *= m; p.z *= m;                                                 \
                 dr *= m;                                                                      \
-            } else if (__builtin_expect(__builtin_amdgcn_ballot_w64(fold) != 0, 0)) {         \
-                RAYN_FOLD_COUNT_HOOK                                                          \
-                /* r2 is not NaN on a folding lane: ONE raw v_max_f32 (fmaxf / med3 lower to three, two of  \
-                   them canonicalising no-ops) */                                             \
-                if (fold) {                                                                   \
-                    const float m = DIV(frs, vmax_raw(r2, mrs));                              \
-                    p.x *= m; p.y *= m; p.z *= m;                                             \
-                    dr *= m;                                                                  \
+            } else {                                                                          \
+                const unsigned long long fold_lanes = __builtin_amdgcn_ballot_w64(fold);      \
+                if (__builtin_expect(fold_lanes != 0, 0)) {                                   \
+                    RAYN_FOLD_COUNT_HOOK                                                      \
+                    if (RAYN_FOLD_DENSE_BELOW > 0 && __builtin_popcountll(fold_lanes) < RAYN_FOLD_DENSE_BELOW) { \
+                        /* few folding lanes: run the block on ALL lanes and select (see RAYN_FOLD_DENSE_BELOW) */ \
+                        const float q = DIV(frs, vmax_raw(r2, mrs));                          \
+                        const float m = fold ? q : 1.0f;                                      \
+                        p.x *= m; p.y *= m; p.z *= m;                                         \
+                        dr *= m;                                                              \
+                    } else if (fold) {                                                        \
+                        /* r2 is not NaN on a folding lane: ONE raw v_max_f32 (fmaxf / med3 lower to three, two of  \
+                           them canonicalising no-ops) */                                     \
+                        const float m = DIV(frs, vmax_raw(r2, mrs));                          \
+                        p.x *= m; p.y *= m; p.z *= m;                                         \
+                        dr *= m;                                                              \
+                    }                                                                         \
                 }                                                                             \
             }                                                                                 \
             p.x = muladd(p.x, s, offset.x);                                                   \

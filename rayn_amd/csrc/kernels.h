@@ -70,6 +70,7 @@ struct Tuning {
     uint32_t prefetch_min_shadow = 32;
     uint32_t ablate = 0;                  // timing-only debug mask for k_shade_setup (see the kernel)
     bool fast_path = true;                // single-SDF specialisations k_extend1 / k_shadow1
+    bool setup_stride = false;            // k_shade_setup as a grid-stride loop (true) or one slot per thread over the upper-bound grid
 };
 
 // sample tables: the reference layout (src/sampler.rs:11-15) + a per-(depth, sample) packed copy built at
@@ -106,6 +107,8 @@ struct Tables {
     void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile, \
                                 const uint32_t* tile_out_base, uint32_t max_slots, uint32_t* qn, uint32_t n_tiles, const uint32_t* tile_total, \
                                 const DCtl* ctl);                                                   \
+    void launch_tile_pixels(hipStream_t s, bool pack, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha, \
+                            float* background, float* normal, float* packed);                       \
     void launch_batch_setup(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t* pgrp_tile, uint32_t* tgb, uint32_t* tgc); \
     void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool, \
                         float* out_color, float* out_alpha, float* out_background, float* out_normal); \

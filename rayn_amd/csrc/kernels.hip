@@ -564,7 +564,10 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
 RD bool all_zero(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 constexpr uint32_t VOL_MEMO_LIGHTS = 7; // per-light volume terms memoised in LDS (3 floats per light and thread)
 
-template <bool COUNT>
+// STRIDE: grid-stride loop over the slots (fixed grid) instead of one slot per thread with a grid sized for the batch's upper
+// bound (surplus blocks exit at once).  Both take the slot count from the control block; which one is faster is a
+// register-pressure question (the loop carries j and the count across a body that already spills) - see Tuning::setup_stride.
+template <bool COUNT, bool STRIDE>
 __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                       uint32_t depth, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl, Pool pool, Nee nee,
                                                       uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt, uint32_t ablate,
@@ -800,6 +803,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     alive[j] = is_alive ? 1 : 0;
     uint64_t m = __ballot(is_alive);
     if (lane == 0) bgrp_cnt[j >> 6] = (uint8_t)__popcll(m);
+    if (!STRIDE) break;
     } // grid-stride loop
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
@@ -1218,6 +1222,28 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-device film assembly (no reference counterpart; tiles are independent, src/film.rs:439-627): a device packs the
+// pixels of the tiles it rendered into one contiguous buffer (10 floats per pixel: Color 3 | Alpha 1 | Background 3 |
+// WorldNormal 3, tile after tile, pixel-major inside a tile like the path pool), the buffer crosses xGMI with ONE peer copy,
+// and device 0 scatters it into the caller's film.  pool_base of the DTile holds the tile's first pixel in the packed buffer.
+// ------------------------------------------------------------------------------------------------
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_tile_pixels(const DTile* __restrict__ tiles, uint32_t width, float* __restrict__ color,
+                                                      float* __restrict__ alpha, float* __restrict__ background, float* __restrict__ normal,
+                                                      float* __restrict__ packed) {
+    const DTile t = tiles[blockIdx.x];
+    const uint32_t npx = t.ew * t.eh;
+    for (uint32_t i = threadIdx.x; i < npx * 10u; i += 256) {
+        const uint32_t lpix = i / 10u, c = i - lpix * 10u;
+        const uint32_t lx = lpix / t.eh, ly = lpix - lx * t.eh;
+        const size_t fi = (size_t)(t.x0 + lx) + (size_t)(t.y0 + ly) * width;
+        float* f = c < 3 ? color + 3 * fi + c : (c == 3 ? alpha + fi : (c < 7 ? background + 3 * fi + (c - 4) : normal + 3 * fi + (c - 7)));
+        float* q = packed + ((size_t)t.pool_base + lpix) * 10u + c;
+        if (PACK) *q = *f; else *f = *q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // test probes (called through the C ABI by tests only): per-lane primitives on arbitrary inputs
 // ------------------------------------------------------------------------------------------------
 __global__ void k_probe_dist(const DScene* __restrict__ scp, uint32_t hit_index, const float* __restrict__ pts, float* __restrict__ out, uint32_t n) {
@@ -1343,9 +1369,15 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
     hooks.before(0);
     const uint32_t shmem = ns > 4 ? VOL_MEMO_LIGHTS * 3 * 256 * 4 : 0; // ns > 4: the volume scatters (volume NEE samples exist)
-    const dim3 sgrid = stride_grid(max_slots, 256, SETUP_BLOCKS);
-    if (count) hipLaunchKernelGGL(k_shade_setup<true>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
-    else hipLaunchKernelGGL(k_shade_setup<false>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+    if (tun.setup_stride) {
+        const dim3 sgrid = stride_grid(max_slots, 256, SETUP_BLOCKS);
+        if (count) hipLaunchKernelGGL((k_shade_setup<true, true>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+        else hipLaunchKernelGGL((k_shade_setup<false, true>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+    } else {
+        const dim3 sgrid = grid_for(max_slots, 256);
+        if (count) hipLaunchKernelGGL((k_shade_setup<true, false>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+        else hipLaunchKernelGGL((k_shade_setup<false, false>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
+    }
     hooks.after(0);
     if (has_sdf) {
         hooks.before(1);
@@ -1366,6 +1398,12 @@ void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* al
                             const uint32_t* tile_out_base, uint32_t max_slots, uint32_t* qn, uint32_t n_tiles, const uint32_t* tile_total,
                             const DCtl* ctl) {
     hipLaunchKernelGGL(k_compact_scatter, stride_grid(max_slots, 256, STREAM_BLOCKS), dim3(256), 0, s, bq, alive, grp_base, grp_tile, tile_out_base, ctl, qn, n_tiles, tile_total);
+}
+void launch_tile_pixels(hipStream_t s, bool pack, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha,
+                        float* background, float* normal, float* packed) {
+    if (!n_tiles) return;
+    if (pack) hipLaunchKernelGGL(k_tile_pixels<true>, dim3(n_tiles), dim3(256), 0, s, tiles, width, color, alpha, background, normal, packed);
+    else hipLaunchKernelGGL(k_tile_pixels<false>, dim3(n_tiles), dim3(256), 0, s, tiles, width, color, alpha, background, normal, packed);
 }
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {

@@ -72,7 +72,7 @@ struct rayn_ctx {
     DScene* d_scene = nullptr;
     float4* d_rec = nullptr; size_t rec_cap = 0; // packed sample records (shared by the workers)
     Worker workers[MAX_WORKERS];
-    hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b = nullptr, ev_ma = nullptr, ev_mb = nullptr; // ev_m*: brackets of a multi-device frame
     rayn_stats stats;
     unsigned long long evals[3] = {0, 0, 0}; // extend, shade_setup (normals), shadow
     bool profiling = false, counting = false;
@@ -81,6 +81,16 @@ struct rayn_ctx {
     int n_workers = 2;
     Tuning tun;
     std::vector<uint32_t> tile_subset; // rayn_hip_set_tile_subset: render only these tiles (sorted)
+    // ---- multi-device context (rayn_hip_create_multi): this ctx is entry 0 and owns the others; every peer is a complete
+    // single-device ctx (own streams, workers, arenas) on its device.  A render deals the share's tiles to the entries, each
+    // renders its list (only_tiles), packs its pixels and sends them to device 0 with one peer copy (render_multi).
+    std::vector<rayn_ctx*> peers;
+    struct PeerBuf { float* tables = nullptr; size_t tables_cap = 0; float* film = nullptr; size_t film_cap = 0; float* packed = nullptr; size_t packed_cap = 0;
+                     DTile* d_tiles = nullptr; size_t tiles_cap = 0; };
+    std::vector<PeerBuf> peer_bufs;                       // on the peer's device
+    float* gather_buf = nullptr; size_t gather_cap = 0;   // on device 0: the packed pixels of all peers
+    DTile* gather_tiles = nullptr; size_t gather_tiles_cap = 0;
+    const std::vector<uint32_t>* only_tiles = nullptr;    // explicit (sorted) tile list of one sub-render
     int trace_tile = -1;             // diagnostics: dump the packet order of this tile (rayn_hip_set_trace_tile)
     std::vector<uint32_t> trace;     // records of 6 u32: depth, object, tile x, tile y, sample, valid
     int fma_policy = 0; // 0: mul_add unfused (reference default build), 1: fused
@@ -482,7 +492,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     std::vector<BatchTile> owned;
     size_t owned_paths = 0;
     for (uint32_t k = 0; k < tiles.size(); k++) {
-        if (!ctx->tile_subset.empty()) { if (!std::binary_search(ctx->tile_subset.begin(), ctx->tile_subset.end(), k)) continue; }
+        if (ctx->only_tiles) { if (!std::binary_search(ctx->only_tiles->begin(), ctx->only_tiles->end(), k)) continue; }
+        else if (!ctx->tile_subset.empty()) { if (!std::binary_search(ctx->tile_subset.begin(), ctx->tile_subset.end(), k)) continue; }
         else if ((k + k / step) % step != p->tile_first) continue; // owner of tile k: rotates by one every 'step' tiles (rayn_hip.h)
         const TileRect& t = tiles[k];
         uint32_t ew = t.x1 - t.x0, eh = t.y1 - t.y0;
@@ -567,6 +578,148 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     return RAYN_OK;
 }
 
+// grow-only device buffer helper
+template <typename T> int ensure(rayn_ctx* ctx, T** ptr, size_t* cap, size_t need) {
+    if (need <= *cap) return RAYN_OK;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr; *cap = 0;
+    if (hipMalloc((void**)ptr, need * sizeof(T)) != hipSuccess) return fail(ctx, RAYN_ERR_OOM, "hipMalloc of a multi-device staging buffer failed");
+    *cap = need;
+    return RAYN_OK;
+}
+
+// Film::render_frame_into over several devices.  All pointers are on devices[0] (= ctx->device); the call is blocking.
+//  1. the share's tiles (tile_first/tile_step or the tile subset) are dealt to the entries: the j-th tile of the share goes
+//     to entry (j + j / N) % N - the same rotating deal the ABI uses between ranks (whole tiles; their cost is very uneven);
+//  2. the sample tables / scramble / filter table are copied to every peer (<= tens of MB), scene descriptors are host data;
+//  3. one host thread per entry drives that entry's own wavefront renderer on its device;
+//  4. every peer packs the pixels of its tiles (10 floats each) and sends them to device 0 with ONE hipMemcpyPeerAsync over
+//     xGMI; device 0 scatters them into the caller's film.  No other data crosses devices.
+int render_multi(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, const float* d_s2, const float* d_scr, const float* d_fis,
+                 float* d_color, float* d_alpha, float* d_bg, float* d_normal, hipStream_t stream) {
+    int rc = validate(ctx, p);
+    if (rc) return rc;
+    if (!d_s1 || !d_s2 || !d_scr || !d_fis || !d_color || !d_alpha || !d_bg || !d_normal) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
+    const size_t N = 1 + ctx->peers.size();
+    const uint32_t step = p->tile_step ? p->tile_step : 1;
+    if (p->tile_first >= step) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile_first must be < tile_step");
+    std::vector<TileRect> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
+    if (!ctx->tile_subset.empty() && ctx->tile_subset.back() >= tiles.size()) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile subset index beyond the frame's tile count");
+    std::vector<std::vector<uint32_t>> lists(N);
+    {
+        size_t j = 0;
+        for (uint32_t k = 0; k < tiles.size(); k++) {
+            if (!ctx->tile_subset.empty()) { if (!std::binary_search(ctx->tile_subset.begin(), ctx->tile_subset.end(), k)) continue; }
+            else if ((k + k / step) % step != p->tile_first) continue;
+            if (tiles[k].x1 <= tiles[k].x0 || tiles[k].y1 <= tiles[k].y0) continue;
+            lists[(j + j / N) % N].push_back(k); // ascending k per entry: the lists are sorted
+            j++;
+        }
+    }
+    const size_t spp = (size_t)p->samples * 4, npx = (size_t)p->width * p->height;
+    const size_t n1 = spp * rayn_sets_1d(p->max_bounces, p->volume_marches), n2 = spp * 2 * rayn_sets_2d(p->max_bounces, p->volume_marches);
+    const size_t n_tab = n1 + n2 + npx + RAYN_FIS_TABLE_SIZE;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(stream)); // the caller's tables are complete before they are copied to the peers
+    // per-peer packed layout: DTile::pool_base = first pixel of the tile in the peer's packed buffer
+    std::vector<std::vector<DTile>> packs(N);
+    std::vector<size_t> pack_px(N, 0), gather_off(N, 0);
+    size_t gather_px = 0, gather_nt = 0;
+    for (size_t e = 1; e < N; e++) {
+        for (uint32_t k : lists[e]) {
+            const TileRect& t = tiles[k];
+            packs[e].push_back(DTile{t.x0, t.y0, t.x1 - t.x0, t.y1 - t.y0, (uint32_t)pack_px[e], 0u, {0, 0}});
+            pack_px[e] += (size_t)(t.x1 - t.x0) * (t.y1 - t.y0);
+        }
+        gather_off[e] = gather_px; gather_px += pack_px[e]; gather_nt += packs[e].size();
+    }
+    rc = ensure(ctx, &ctx->gather_buf, &ctx->gather_cap, gather_px * 10);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->gather_tiles, &ctx->gather_tiles_cap, gather_nt);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ctx->ev_ma, stream));
+    std::vector<int> rcs(N, 0);
+    std::vector<std::string> errs(N);
+    auto run_entry = [&](size_t e) {
+        rayn_ctx* c = e == 0 ? ctx : ctx->peers[e - 1];
+        auto bail = [&](int code, const std::string& m) { rcs[e] = code; errs[e] = m; };
+        if (hipSetDevice(c->device) != hipSuccess) return bail(RAYN_ERR_HIP, "hipSetDevice");
+        c->only_tiles = &lists[e];
+        if (e == 0) {
+            rcs[0] = render_device(ctx, p, d_s1, d_s2, d_scr, d_fis, d_color, d_alpha, d_bg, d_normal, stream);
+            ctx->only_tiles = nullptr;
+            if (rcs[0]) errs[0] = ctx->err;
+            return;
+        }
+        rayn_ctx::PeerBuf& B = ctx->peer_bufs[e - 1];
+        int r = ensure(c, &B.tables, &B.tables_cap, n_tab);
+        if (!r) r = ensure(c, &B.film, &B.film_cap, npx * RAYN_FILM_FLOATS_PER_PIXEL);
+        if (!r) r = ensure(c, &B.packed, &B.packed_cap, std::max<size_t>(pack_px[e], 1) * 10);
+        if (!r) r = ensure(c, &B.d_tiles, &B.tiles_cap, std::max<size_t>(packs[e].size(), 1));
+        if (r) { c->only_tiles = nullptr; return bail(r, c->err); }
+        float *t1 = B.tables, *t2 = t1 + n1, *tscr = t2 + n2, *tfis = tscr + npx;
+        float *fc = B.film, *fa = fc + 3 * npx, *fb = fa + npx, *fn = fb + 3 * npx;
+        hipError_t he = hipMemcpyPeerAsync(t1, c->device, d_s1, ctx->device, n1 * 4, c->stream);
+        if (he == hipSuccess) he = hipMemcpyPeerAsync(t2, c->device, d_s2, ctx->device, n2 * 4, c->stream);
+        if (he == hipSuccess) he = hipMemcpyPeerAsync(tscr, c->device, d_scr, ctx->device, npx * 4, c->stream);
+        if (he == hipSuccess) he = hipMemcpyPeerAsync(tfis, c->device, d_fis, ctx->device, RAYN_FIS_TABLE_SIZE * 4, c->stream);
+        if (he != hipSuccess) { c->only_tiles = nullptr; return bail(RAYN_ERR_HIP, std::string("table broadcast: ") + hipGetErrorString(he)); }
+        r = render_device(c, p, t1, t2, tscr, tfis, fc, fa, fb, fn, c->stream);
+        c->only_tiles = nullptr;
+        if (r) return bail(r, c->err);
+        if (!packs[e].empty()) {
+            he = hipMemcpyAsync(B.d_tiles, packs[e].data(), packs[e].size() * sizeof(DTile), hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess) {
+                rayn_p0::launch_tile_pixels(c->stream, true, B.d_tiles, (uint32_t)packs[e].size(), p->width, fc, fa, fb, fn, B.packed);
+                he = hipMemcpyPeerAsync(ctx->gather_buf + gather_off[e] * 10, ctx->device, B.packed, c->device, pack_px[e] * 40, c->stream); // the one gather copy
+            }
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            if (he != hipSuccess) return bail(RAYN_ERR_HIP, std::string("film gather: ") + hipGetErrorString(he));
+        }
+    };
+    {
+        std::vector<std::thread> threads;
+        for (size_t e = 1; e < N; e++) threads.emplace_back(run_entry, e);
+        run_entry(0);
+        for (auto& t : threads) t.join();
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    for (size_t e = 0; e < N; e++) if (rcs[e]) return fail(ctx, rcs[e], "device entry " + std::to_string(e) + ": " + errs[e]);
+    // scatter the peers' pixels into the caller's film (device 0)
+    size_t t_off = 0;
+    for (size_t e = 1; e < N; e++) {
+        if (packs[e].empty()) continue;
+        HIPCHK(hipMemcpyAsync(ctx->gather_tiles + t_off, packs[e].data(), packs[e].size() * sizeof(DTile), hipMemcpyHostToDevice, stream));
+        rayn_p0::launch_tile_pixels(stream, false, ctx->gather_tiles + t_off, (uint32_t)packs[e].size(), p->width, d_color, d_alpha, d_bg, d_normal,
+                                    ctx->gather_buf + gather_off[e] * 10);
+        t_off += packs[e].size();
+    }
+    HIPCHK(hipEventRecord(ctx->ev_mb, stream));
+    HIPCHK(hipStreamSynchronize(stream)); // also keeps 'packs' alive until the tile lists have been copied
+    // statistics: sums over the entries; ms_total = the whole multi-device frame on device 0's clock
+    rayn_stats total = ctx->stats;
+    for (rayn_ctx* c : ctx->peers) {
+        const rayn_stats& s = c->stats;
+        total.paths += s.paths; total.segments += s.segments; total.shaded_slots += s.shaded_slots; total.tiles += s.tiles; total.batches += s.batches;
+        total.launches_extend += s.launches_extend; total.launches_shade += s.launches_shade; total.shadow_jobs += s.shadow_jobs;
+        total.queue_bytes_bin += s.queue_bytes_bin; total.queue_bytes_compact += s.queue_bytes_compact;
+        total.ms_raygen += s.ms_raygen; total.ms_extend += s.ms_extend; total.ms_bin += s.ms_bin; total.ms_shade += s.ms_shade; total.ms_compact += s.ms_compact;
+        total.ms_resolve += s.ms_resolve; total.ms_shadow += s.ms_shadow; total.ms_finish += s.ms_finish;
+        for (int k = 0; k < 3; k++) ctx->evals[k] += c->evals[k];
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev_ma, ctx->ev_mb);
+    total.ms_total = ms;
+    ctx->stats = total;
+    return RAYN_OK;
+}
+
+int render_any(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, const float* d_s2, const float* d_scr, const float* d_fis,
+               float* d_color, float* d_alpha, float* d_bg, float* d_normal, hipStream_t stream) {
+    if (ctx && !ctx->peers.empty()) return render_multi(ctx, p, d_s1, d_s2, d_scr, d_fis, d_color, d_alpha, d_bg, d_normal, stream);
+    return render_device(ctx, p, d_s1, d_s2, d_scr, d_fis, d_color, d_alpha, d_bg, d_normal, stream);
+}
+
 } // namespace
 
 extern "C" {
@@ -582,12 +735,13 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     memset(&ctx->stats, 0, sizeof ctx->stats);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&ctx->stream) == hipSuccess &&
               hipMalloc((void**)&ctx->d_scene, sizeof(DScene)) == hipSuccess && hipEventCreate(&ctx->ev_a) == hipSuccess &&
-              hipEventCreate(&ctx->ev_b) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+              hipEventCreate(&ctx->ev_b) == hipSuccess && hipEventCreate(&ctx->ev_ma) == hipSuccess && hipEventCreate(&ctx->ev_mb) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (Worker& w : ctx->workers)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess && hipMalloc((void**)&w.d_evals, 32) == hipSuccess &&
              hipHostMalloc((void**)&w.h_totals, 16) == hipSuccess && hipHostMalloc((void**)&w.h_ctl, sizeof(DCtl)) == hipSuccess && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { rayn_hip_destroy(ctx); return RAYN_ERR_HIP; }
     if (const char* e = getenv("RAYN_HIP_WORKERS")) ctx->n_workers = atoi(e);
+    if (const char* e = getenv("RAYN_HIP_WORKER_MIN_PATHS")) ctx->two_worker_min_paths = (size_t)atoll(e); // 0 forces n_workers
     if (const char* e = getenv("RAYN_HIP_BATCH_PATHS")) { long long v = atoll(e); if (v >= 4096) ctx->batch_paths = (size_t)v; }
     if (const char* e = getenv("RAYN_HIP_PROFILE")) ctx->profiling = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_REFILL_EXTEND")) ctx->tun.refill_min_extend = (uint32_t)std::max(1, atoi(e));
@@ -596,14 +750,59 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     if (const char* e = getenv("RAYN_HIP_PREFETCH_SHADOW")) ctx->tun.prefetch_min_shadow = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("RAYN_HIP_ABLATE")) ctx->tun.ablate = (uint32_t)atoi(e);
     if (const char* e = getenv("RAYN_HIP_FAST_PATH")) ctx->tun.fast_path = atoi(e) != 0;
+    if (const char* e = getenv("RAYN_HIP_SETUP_STRIDE")) ctx->tun.setup_stride = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_PERSISTENT_BLOCKS")) ctx->tun.persistent_blocks = (uint32_t)std::max(1, atoi(e));
     *out = ctx;
     return RAYN_OK;
 }
 
+int rayn_hip_create_multi(const int* devices, int n_devices, rayn_ctx** out) {
+    if (!out) return RAYN_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) return RAYN_ERR_INVALID_ARG;
+    rayn_ctx* ctx = nullptr;
+    int rc = rayn_hip_create(devices[0], &ctx);
+    if (rc) return rc;
+    for (int i = 1; i < n_devices; i++) {
+        rayn_ctx* c = nullptr;
+        rc = rayn_hip_create(devices[i], &c);
+        if (rc) { rayn_hip_destroy(ctx); return rc; }
+        ctx->peers.push_back(c);
+        if (devices[i] != devices[0]) { // direct xGMI copies; "already enabled" is fine, and without access the runtime stages the copy
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
+                (void)hipSetDevice(devices[0]); (void)hipDeviceEnablePeerAccess(devices[i], 0);
+                (void)hipSetDevice(devices[i]); (void)hipDeviceEnablePeerAccess(devices[0], 0);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    ctx->peer_bufs.resize(ctx->peers.size());
+    (void)hipSetDevice(devices[0]);
+    *out = ctx;
+    return RAYN_OK;
+}
+
+int rayn_hip_device_count(const rayn_ctx* ctx) { return ctx ? (int)(1 + ctx->peers.size()) : 0; }
+
 void rayn_hip_destroy(rayn_ctx* ctx) {
     if (!ctx) return;
+    for (size_t i = 0; i < ctx->peers.size(); i++) {
+        rayn_ctx* c = ctx->peers[i];
+        (void)hipSetDevice(c->device);
+        if (i < ctx->peer_bufs.size()) {
+            rayn_ctx::PeerBuf& B = ctx->peer_bufs[i];
+            if (B.tables) (void)hipFree(B.tables);
+            if (B.film) (void)hipFree(B.film);
+            if (B.packed) (void)hipFree(B.packed);
+            if (B.d_tiles) (void)hipFree(B.d_tiles);
+        }
+        rayn_hip_destroy(c);
+    }
+    ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
+    if (ctx->gather_buf) (void)hipFree(ctx->gather_buf);
+    if (ctx->gather_tiles) (void)hipFree(ctx->gather_tiles);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Worker& w : ctx->workers) {
         if (w.stream) (void)hipStreamSynchronize(w.stream);
@@ -619,6 +818,8 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    if (ctx->ev_ma) (void)hipEventDestroy(ctx->ev_ma);
+    if (ctx->ev_mb) (void)hipEventDestroy(ctx->ev_mb);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -634,6 +835,7 @@ int rayn_hip_upload_world(rayn_ctx* ctx, const rayn_world_desc* world) {
         return fail(ctx, RAYN_ERR_INVALID_ARG, "world counts out of range");
     ctx->world = *world;
     ctx->have_world = true;
+    for (rayn_ctx* c : ctx->peers) { c->world = *world; c->have_world = true; }
     return RAYN_OK;
 }
 
@@ -642,7 +844,7 @@ int rayn_hip_render_frame_device(rayn_ctx* ctx, const rayn_frame_params* p, cons
                                  float* d_out_background, float* d_out_normal, void* hip_stream) {
     if (!ctx) return RAYN_ERR_INVALID_ARG;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    return render_device(ctx, p, d_samples_1d, d_samples_2d, d_scramble, d_fis_table, d_out_color, d_out_alpha, d_out_background, d_out_normal, s);
+    return render_any(ctx, p, d_samples_1d, d_samples_2d, d_scramble, d_fis_table, d_out_color, d_out_alpha, d_out_background, d_out_normal, s);
 }
 
 int rayn_hip_render_frame(rayn_ctx* ctx, const rayn_frame_params* p, const float* samples_1d, const float* samples_2d, const float* scramble,
@@ -663,7 +865,7 @@ int rayn_hip_render_frame(rayn_ctx* ctx, const rayn_frame_params* p, const float
     up(d1, samples_1d, n1); up(d2, samples_2d, n2); up(dscr, scramble, npx); up(dfis, fis_table, RAYN_FIS_TABLE_SIZE);
     up(dc, out_color, 3 * npx); up(da, out_alpha, npx); up(db, out_background, 3 * npx); up(dn, out_normal, 3 * npx); // keep un-owned pixels
     if (e != hipSuccess) { hipFree(d); return fail(ctx, RAYN_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); }
-    rc = render_device(ctx, p, d1, d2, dscr, dfis, dc, da, db, dn, ctx->stream);
+    rc = render_any(ctx, p, d1, d2, dscr, dfis, dc, da, db, dn, ctx->stream);
     if (rc == RAYN_OK) {
         auto down = [&](float* dst, const float* src, size_t n) { if (e == hipSuccess) e = hipMemcpy(dst, src, n * 4, hipMemcpyDeviceToHost); };
         down(out_color, dc, 3 * npx); down(out_alpha, da, npx); down(out_background, db, 3 * npx); down(out_normal, dn, 3 * npx);
@@ -685,6 +887,7 @@ int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals) {
     if (!ctx) return RAYN_ERR_INVALID_ARG;
     ctx->profiling = timing != 0;
     ctx->counting = count_evals != 0;
+    for (rayn_ctx* c : ctx->peers) { c->profiling = ctx->profiling; c->counting = ctx->counting; }
     return RAYN_OK;
 }
 int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]) {
@@ -695,6 +898,7 @@ int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]) {
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths) {
     if (!ctx || paths < 4096) return RAYN_ERR_INVALID_ARG;
     ctx->batch_paths = (size_t)paths;
+    for (rayn_ctx* c : ctx->peers) c->batch_paths = (size_t)paths;
     return RAYN_OK;
 }
 
@@ -768,6 +972,7 @@ int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths) {
     if (!ctx || n_workers < 1 || n_workers > MAX_WORKERS) return RAYN_ERR_INVALID_ARG;
     ctx->n_workers = n_workers;
     ctx->two_worker_min_paths = (size_t)min_paths;
+    for (rayn_ctx* c : ctx->peers) { c->n_workers = n_workers; c->two_worker_min_paths = (size_t)min_paths; }
     return RAYN_OK;
 }
 int rayn_hip_set_tile_subset(rayn_ctx* ctx, const uint32_t* tiles, uint32_t n) {
@@ -793,6 +998,7 @@ int rayn_hip_fma_policy(void) { return 0; }
 int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy) {
     if (!ctx || (policy != 0 && policy != 1)) return RAYN_ERR_INVALID_ARG;
     ctx->fma_policy = policy;
+    for (rayn_ctx* c : ctx->peers) c->fma_policy = policy;
     return RAYN_OK;
 }
 size_t rayn_hip_sizeof(int which) {

@@ -49,13 +49,24 @@ class Context:
     """One rayn_ctx (one GPU).  Fails loudly when the HIP library or a GPU is missing."""
 
     def __init__(self, device=0):
+        """device: one GPU index, or a list of indices for a multi-device context (rayn_hip_create_multi; buffers passed
+        to render_device then live on the first one)."""
         self._L = lib()
         h = C.c_void_p()
-        rc = self._L.rayn_hip_create(device, C.byref(h))
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*device)
+            rc = self._L.rayn_hip_create_multi(ids, len(device), C.byref(h))
+            first = device[0] if len(device) else 0
+        else:
+            rc = self._L.rayn_hip_create(device, C.byref(h))
+            first = device
         if rc != 0:
             raise RaynHipError(f"rayn_hip_create(device={device}) failed with {rc} (no usable GPU?)")
         self.h = h
-        self.device = device
+        self.device = first
+
+    def device_count(self):
+        return self._L.rayn_hip_device_count(self.h)
 
     def _chk(self, rc):
         if rc != 0:
