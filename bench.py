@@ -26,6 +26,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+def kernel_source_hash():
+    """sha256 over the kernel sources: PMC traffic files under profiles/ are stamped with it, so a stale file is detected."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "device_core.h", "kernels.h", "device_scene.h", "rayn_hip.hip"):
+        h.update(open(os.path.join(ROOT, "rayn_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 FLOP_PER_DIST = 404.0  # MandelBox::dist, 12 iterations x 33 + 8, fma = 2 (SURVEY.md section 8d)
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= f32-input MFMA peak)
 HBM_PEAK_GBS = 8000.0
@@ -142,7 +151,8 @@ def main():
         achieved = FLOP_PER_DIST * evals / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # "bound" uses the contract's vocabulary (hbm | mfma = the compute roof); the compute roof of this path is the FP32
         # VECTOR pipe - nothing here is a dense contraction, no MFMA instruction is issued (see bound_detail)
-        roofline = {"kernel": f"k_{dom}", "bound": "mfma", "bound_detail": "compute-bound on the FP32 VALU (divergent scalar math, no MFMA issued); "
+        kname = {"extend": "k_extend1", "shadow": "k_shadow1", "shade_setup": "k_shade_setup"}[dom]
+        roofline = {"kernel": f"{kname} [FP32 VALU-bound; no MFMA instruction is issued anywhere on this path]", "bound": "mfma", "bound_detail": "compute-bound on the FP32 VALU (divergent scalar math, no MFMA issued); "
                     "peak = MI355X dense FP32 peak, 157.3 TFLOP/s for the vector pipe and for f32-input MFMA alike",
                     "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
@@ -160,18 +170,29 @@ def main():
             "compact(k_scan_tile+k_tile_prefix+memset+k_compact_scatter)": (st["ms_compact"], st["queue_bytes_compact"]),
             "k_resolve": (st["ms_resolve"], 37.0 * npool + 40.0 * W * H / world),  # col0 + aov + termination record per path, film out
         }
-        roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": {}}
+        qk["k_shadow1 (queue side: 4 B ref + 32 B segment in, 1 B visibility out per shadow job; the kernel itself is VALU-bound)"] = (st["ms_shadow"], 37.0 * st["shadow_jobs"])
+        ns_vol = 4 * p.volume_marches if wd.has_scattering else 0
+        # finish side of the NEE-record round trip, per valid segment: slot ref 4 + flags 1 + pool in/out 48 + T 4 + new throughput 12
+        # + per light sample (x 12, pdf 4, visibility 1) + 4 per volume sample (transmittance to the sample point); surface records
+        # only exist for light-receiving hits, so this is an upper estimate of the algorithmic bytes
+        qk["k_shade_finish (upper estimate)"] = (st["ms_finish"], float(st["segments"]) * (69 + (4 + ns_vol) * 17 + ns_vol * 4))
+        roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shadow_jobs": st["shadow_jobs"], "kernels": {}}
         for name, (ms_k, nbytes) in qk.items():
             ach = nbytes / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
             roofline_hbm["kernels"][name] = {"ms": round(ms_k, 3), "algorithmic_bytes": nbytes, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
-        pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_{args.workload}.json")
+        # PMC traffic is measured by separate rocprofv3 --pmc passes (tools/gpu_pmc_round.sh) and committed under profiles/ with the
+        # hash of the kernel sources it was taken on; a file that does not match the sources of THIS build is not quoted.
+        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_hbm_{args.workload}.json")
         if os.path.exists(pmc_path) and world == 1 and args.fma_policy == 0:
-            pmc = json.load(open(pmc_path))["kernels"]
-            dk = {"extend": "k_extend1", "shadow": "k_shadow1", "shade_setup": "k_shade_setup"}[dom]
-            if dk in pmc and "hbm_bytes_per_launch" in pmc[dk]:
-                roofline["traffic"] = pmc[dk]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = f"profiles/r01_pmc_hbm_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
-            roofline_hbm["pmc_traffic"] = {k: {"hbm_bytes": v["hbm_bytes"], "GBps": round(v.get("hbm_GBps", 0.0), 1)} for k, v in pmc.items()}
+            pj = json.load(open(pmc_path))
+            if pj.get("source_hash") == kernel_source_hash():
+                pmc = pj["kernels"]
+                if kname in pmc and "hbm_bytes_per_launch" in pmc[kname]:
+                    roofline["traffic"] = pmc[kname]["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = f"profiles/r02_pmc_hbm_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, kernel sources {pj['source_hash']})"
+                roofline_hbm["pmc_traffic"] = {k: {"hbm_bytes": v["hbm_bytes"], "GBps": round(v.get("hbm_GBps", 0.0), 1)} for k, v in pmc.items()}
+            else:
+                roofline["traffic_note"] = f"profiles/r02_pmc_hbm_{args.workload}.json was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"
         kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_shadow", "ms_finish", "ms_compact", "ms_resolve", "ms_total")}
     else:
         kernel_ms = None
@@ -180,11 +201,13 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import oracle_py as O
         threads = os.cpu_count() or 1
-        # The oracle runs a tile serially on one thread (like the reference).  A 16x16 tile of this workload is minutes of
-        # one core at 1024 spp, so the CPU sample uses smaller tiles (a legal Film::render_frame_into tile_size) that hold
-        # <= 4096 paths each: same scene, resolution, spp, bounces and per-path work, bounded wall time.
+        # The oracle runs a tile serially on one thread (like the reference).  A 16x16 tile of this workload is about a minute
+        # of one core at 1024 spp, so the CPU sample uses smaller tiles (a legal Film::render_frame_into tile_size) that hold
+        # <= 16384 paths each: same scene, resolution, spp, bounces and per-path work, bounded wall time and a balanced thread
+        # pool.  (Packet composition is per tile, so the CPU side's packets differ from the GPU's 16x16 tiles - stated in the
+        # emitted record; parity at 16x16 is what tests/test_config_digests.py checks.)
         ct = 16
-        while ct > 1 and ct * ct * spp > 4096:
+        while ct > 1 and ct * ct * spp > 16384:
             ct //= 2
         p0 = rayn_amd.frame_params(W, H, samples, bounces, tile_size=(ct, ct))
         n_tiles = rayn_amd._lib.lib().rayn_tile_count(W, H, p0.tile_w, p0.tile_h)
@@ -198,8 +221,10 @@ def main():
         k = int(min(n_tiles, max(threads, k_cal * args.cpu_seconds / max(t_cal, 1e-3))))
         t_cpu, paths_cpu, k_used = run(k)
         cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
+                        "tile": [ct, ct], "gpu_tile": [p.tile_w, p.tile_h],
                         "sample": f"{k_used} of {n_tiles} {ct}x{ct}-pixel tiles (evenly spread, {paths_cpu} paths) of the same workload, C++ oracle "
-                                  f"(restatement of rayn's CPU path; rayn itself cannot be built here), {t_cpu:.1f} s"}
+                                  f"(restatement of rayn's CPU path; rayn itself cannot be built here), {t_cpu:.1f} s; the GPU renders "
+                                  f"{p.tile_w}x{p.tile_h} tiles (same per-path work, different packet grouping)"}
 
     if rank == 0:
         out = {

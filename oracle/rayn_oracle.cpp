@@ -1251,6 +1251,53 @@ void oracle_detmath(uint32_t op, const float* a, const float* b, float* out, uin
     }
 }
 int oracle_fma_policy() { return RAYN_FMA_POLICY; }
+
+/* Film::save_to's per-pixel post-process, src/film.rs:205-378 (N3), restated arm by arm.  kind: 0 Color, 1 Alpha,
+ * 2 Background, 3 WorldNormal (ChannelKind, src/film.rs:103-120).  have_*: which channels the film holds.  Writes the 8-bit
+ * image rows top-down (idx = x + (h-1-y)*w, :236) into out (1, 3 or 4 bytes per pixel) and returns the bytes per pixel, or
+ * -1 where the reference returns Err ("insufficient channels" :283-287 / "didn't exist" :292-296,316-320,341-345).
+ * Srgb::saturated / gamma_corrected: src/spectrum.rs:30-40; powf = the pinned dm_powf.  Quantisation
+ * `(v * 255.0).min(255.0).max(0.0) as u8` with Rust's f32::min/max (a NaN operand yields the OTHER operand) and the
+ * saturating float -> u8 cast. */
+static inline float rust_min(float a, float b) { return a != a ? b : (b != b ? a : (a < b ? a : b)); }
+static inline float rust_max(float a, float b) { return a != a ? b : (b != b ? a : (a > b ? a : b)); }
+static inline uint8_t quant8(float v) { float q = rust_max(rust_min(v * 255.0f, 255.0f), 0.0f); return (uint8_t)q; }
+static inline float saturate1(float x) { return rust_min(rust_max(x, 0.0f), 1.0f); }
+static inline float gamma1(float x, float gamma) { return dm_powf(x, 1.0f / gamma); }
+int oracle_save_to_pixels(uint32_t kind, int have_color, int have_alpha, int have_background, int have_normal, int transparent_background,
+                          uint32_t w, uint32_t h, const float* color, const float* alpha, const float* background, const float* normal, uint8_t* out) {
+    int bpp = -1;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const size_t idx = (size_t)x + (size_t)(h - 1 - y) * w, o = (size_t)x + (size_t)y * w;
+            if (kind == 0) {
+                if (have_color && have_alpha && transparent_background) { /* :231-254 */
+                    bpp = 4;
+                    for (int c = 0; c < 3; c++) out[o * 4 + c] = quant8(gamma1(saturate1(color[3 * idx + c]), 2.2f));
+                    out[o * 4 + 3] = quant8(alpha[idx]);
+                } else if (have_color && have_background && !transparent_background) { /* :255-277 */
+                    bpp = 3;
+                    for (int c = 0; c < 3; c++) out[o * 3 + c] = quant8(gamma1(saturate1(color[3 * idx + c] + background[3 * idx + c]), 2.2f));
+                } else if (have_color && !have_background && !transparent_background) { /* :278-ish: gamma WITHOUT saturate */
+                    bpp = 3;
+                    for (int c = 0; c < 3; c++) out[o * 3 + c] = quant8(gamma1(color[3 * idx + c], 2.2f));
+                } else return -1;
+            } else if (kind == 2) {
+                if (!have_background) return -1;
+                bpp = 3;
+                for (int c = 0; c < 3; c++) out[o * 3 + c] = quant8(gamma1(saturate1(background[3 * idx + c]), 2.2f));
+            } else if (kind == 3) {
+                if (!have_normal) return -1;
+                bpp = 3;
+                for (int c = 0; c < 3; c++) out[o * 3 + c] = quant8(normal[3 * idx + c] * 0.5f + 0.5f);
+            } else {
+                if (!have_alpha) return -1;
+                bpp = 1;
+                out[o] = quant8(alpha[idx]);
+            }
+        }
+    return bpp;
+}
 /* DIAGNOSTICS: install (on != 0) / remove the shadow-segment sink; oracle_take_shadow_sink copies up to cap floats (records of 8)
  * and returns the float count.  Used by tools/coherence_sim.py to study wave coherence of the shadow marches on the CPU. */
 void oracle_set_shadow_sink(int on) {

@@ -233,7 +233,8 @@ int validate(rayn_ctx* ctx, const rayn_frame_params* p) {
     if (p->volume_marches < 2 || p->volume_marches > 4) return fail(ctx, RAYN_ERR_INVALID_ARG, "volume_marches must be in [2,4] (samples_1d[3],[4] are indexed, src/integrator.rs:138,175)");
     if (p->max_bounces > 120) return fail(ctx, RAYN_ERR_INVALID_ARG, "max_bounces > 120 does not fit the 7-bit depth field of the termination record");
     if (p->samples > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "spp > 4096 unsupported (film resolve sorts a pixel's samples in LDS)");
-    if (p->tile_w * p->tile_h > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile larger than 1024 pixels unsupported");
+    if ((uint64_t)p->tile_w * (uint64_t)p->tile_h > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile larger than 1024 pixels unsupported");
+    if ((uint64_t)p->width * (uint64_t)p->height >= ((uint64_t)1 << 31)) return fail(ctx, RAYN_ERR_INVALID_ARG, "film larger than 2^31 pixels unsupported (32-bit pixel indices)");
     return RAYN_OK;
 }
 
@@ -722,6 +723,15 @@ int render_any(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, con
 
 } // namespace
 
+namespace {
+struct DevBuf { // hipMalloc'ed scratch of a probe call, released on every exit path
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <typename T> T* as() const { return (T*)p; }
+};
+} // namespace
+
 extern "C" {
 
 int rayn_hip_create(int device, rayn_ctx** out) {
@@ -903,6 +913,7 @@ int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths) {
 }
 
 /* ---- test probes: per-lane device primitives on caller data (HOST pointers) ---- */
+
 static int probe_common(rayn_ctx* ctx, const rayn_frame_params* p) {
     int rc = validate(ctx, p);
     if (rc) return rc;
@@ -916,56 +927,57 @@ static int probe_common(rayn_ctx* ctx, const rayn_frame_params* p) {
 int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t hitable_index, const float* pts, float* out, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
+    if (hitable_index >= ctx->world.n_hitables || ctx->world.hitables[hitable_index].kind != RAYN_HITABLE_TRACED_SDF)
+        return fail(ctx, RAYN_ERR_INVALID_ARG, "hitable_index does not name a TracedSDF of the uploaded world");
+    if (!pts || !out) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
     const KernelSet K = kernel_set(ctx->fma_policy);
-    float *d_in = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc((void**)&d_in, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
-    HIPCHK(hipMemcpy(d_in, pts, (size_t)n * 12, hipMemcpyHostToDevice));
-    K.probe_dist(ctx->stream, ctx->d_scene, hitable_index, d_in, d_out, n);
+    DevBuf d_in, d_out;
+    HIPCHK(d_in.alloc((size_t)n * 12)); HIPCHK(d_out.alloc((size_t)n * 4));
+    HIPCHK(hipMemcpy(d_in.p, pts, (size_t)n * 12, hipMemcpyHostToDevice));
+    K.probe_dist(ctx->stream, ctx->d_scene, hitable_index, d_in.as<float>(), d_out.as<float>(), n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_in); hipFree(d_out);
+    HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RAYN_OK;
 }
 int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth, const float* org, const float* dir, float* out_t,
                                uint32_t* out_obj, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
+    if (!org || !dir || !out_t || !out_obj) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
     const KernelSet K = kernel_set(ctx->fma_policy);
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; uint32_t* d_obj = nullptr;
-    HIPCHK(hipMalloc((void**)&d_o, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_d, (size_t)n * 12));
-    HIPCHK(hipMalloc((void**)&d_t, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_obj, (size_t)n * 4));
-    HIPCHK(hipMemcpy(d_o, org, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice));
-    K.probe_closest(ctx->stream, ctx->d_scene, depth, d_o, d_d, d_t, d_obj, n);
+    DevBuf d_o, d_d, d_t, d_obj;
+    HIPCHK(d_o.alloc((size_t)n * 12)); HIPCHK(d_d.alloc((size_t)n * 12)); HIPCHK(d_t.alloc((size_t)n * 4)); HIPCHK(d_obj.alloc((size_t)n * 4));
+    HIPCHK(hipMemcpy(d_o.p, org, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_d.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    K.probe_closest(ctx->stream, ctx->d_scene, depth, d_o.as<float>(), d_d.as<float>(), d_t.as<float>(), d_obj.as<uint32_t>(), n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_obj, d_obj, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_obj);
+    HIPCHK(hipMemcpy(out_t, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_obj, d_obj.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RAYN_OK;
 }
 int rayn_hip_probe_occluded(rayn_ctx* ctx, const rayn_frame_params* p, const float* start, const float* end, float* out, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
+    if (!start || !end || !out) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
     const KernelSet K = kernel_set(ctx->fma_policy);
-    float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc((void**)&d_a, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 12)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
-    HIPCHK(hipMemcpy(d_a, start, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, end, (size_t)n * 12, hipMemcpyHostToDevice));
-    K.probe_occluded(ctx->stream, ctx->d_scene, d_a, d_b, d_out, n);
+    DevBuf d_a, d_b, d_out;
+    HIPCHK(d_a.alloc((size_t)n * 12)); HIPCHK(d_b.alloc((size_t)n * 12)); HIPCHK(d_out.alloc((size_t)n * 4));
+    HIPCHK(hipMemcpy(d_a.p, start, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b.p, end, (size_t)n * 12, hipMemcpyHostToDevice));
+    K.probe_occluded(ctx->stream, ctx->d_scene, d_a.as<float>(), d_b.as<float>(), d_out.as<float>(), n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_a); hipFree(d_b); hipFree(d_out);
+    HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RAYN_OK;
 }
 int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const float* b, float* out, uint32_t n) {
     if (!ctx) return RAYN_ERR_INVALID_ARG;
+    if (!a || !b || !out) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
     const KernelSet K = kernel_set(ctx->fma_policy);
     HIPCHK(hipSetDevice(ctx->device));
-    float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
+    DevBuf d_a, d_b, d_out;
     const size_t na = (op >= 9 && op <= 12) ? (size_t)n * 3 : (size_t)n; // ops 9..12 read xyz triples from a
-    HIPCHK(hipMalloc((void**)&d_a, na * 4)); HIPCHK(hipMalloc((void**)&d_b, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
-    HIPCHK(hipMemcpy(d_a, a, na * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b, b, (size_t)n * 4, hipMemcpyHostToDevice));
-    K.probe_detmath(ctx->stream, op, d_a, d_b, d_out, n);
+    HIPCHK(d_a.alloc(na * 4)); HIPCHK(d_b.alloc((size_t)n * 4)); HIPCHK(d_out.alloc((size_t)n * 4));
+    HIPCHK(hipMemcpy(d_a.p, a, na * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b.p, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    K.probe_detmath(ctx->stream, op, d_a.as<float>(), d_b.as<float>(), d_out.as<float>(), n);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_a); hipFree(d_b); hipFree(d_out);
+    HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RAYN_OK;
 }
 int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths) {

@@ -1,8 +1,8 @@
 """Multi-GPU film partition: one process per GPU, whole 16x16 tiles dealt round-robin to ranks
 (tile k belongs to rank (k + k // world) % world — tiles are fully independent, src/film.rs:439-627, and their
 cost is very uneven, so ranks are interleaved and the interleave rotates every `world` tiles), and ONE gather of each rank's owned pixels to
-rank 0 at frame end (RCCL over xGMI with backend "nccl"; gloo on CPU in the tests).  No other
-collective touches the data path."""
+rank 0 at frame end (grouped point-to-point transfers: RCCL over xGMI with backend "nccl"; gloo on CPU in the tests).  No other
+communication touches the data path.  (Inside ONE process the C ABI does the same with peer copies: rayn_hip_create_multi.)"""
 import numpy as np
 
 
@@ -25,50 +25,48 @@ def owned_pixels(width, height, tile_w, tile_h, rank, world):
 
 
 class FilmGather:
-    """Precomputed index plan for gathering a tile-partitioned film onto rank 0."""
+    """Index plan + PREALLOCATED buffers for gathering a tile-partitioned film onto rank 0 (nothing is allocated inside a
+    frame).  Every rank sends exactly its own pixel count (10 floats per pixel) with one point-to-point transfer; rank 0 posts
+    all receives as one batch (a grouped ncclSend/ncclRecv on RCCL = the frame's single collective step) and scatters the
+    pixels into its own film, which already holds rank 0's tiles."""
 
     def __init__(self, width, height, tile_size, rank, world, device):
         import torch
         self.rank, self.world, self.n_pixels = rank, world, width * height
         per_rank = [owned_pixels(width, height, tile_size[0], tile_size[1], r, world) for r in range(world)]
-        self.count_max = max(len(p) for p in per_rank)
+        self.counts = [len(p) for p in per_rank]
         self.mine = torch.from_numpy(per_rank[rank]).to(device)
-        self.all = [torch.from_numpy(p).to(device) for p in per_rank] if rank == 0 else None
         self.device = device
+        self.send = torch.empty(self.counts[rank], 10, dtype=torch.float32, device=device) if rank != 0 else None
+        if rank == 0:
+            self.all = [torch.from_numpy(p).to(device) for p in per_rank]
+            self.recv = [None] + [torch.empty(self.counts[r], 10, dtype=torch.float32, device=device) for r in range(1, world)]
 
     def pack(self, film):
-        """[count_max, 10] = Color 3 | Alpha 1 | Background 3 | WorldNormal 3 of the owned pixels."""
-        import torch
-        buf = torch.zeros(self.count_max, 10, dtype=torch.float32, device=self.device)
-        n = self.mine.numel()
-        buf[:n, 0:3] = film["color"].view(-1, 3)[self.mine]
-        buf[:n, 3] = film["alpha"].view(-1)[self.mine]
-        buf[:n, 4:7] = film["background"].view(-1, 3)[self.mine]
-        buf[:n, 7:10] = film["normal"].view(-1, 3)[self.mine]
+        """[count, 10] = Color 3 | Alpha 1 | Background 3 | WorldNormal 3 of the owned pixels, into the preallocated buffer."""
+        buf = self.send
+        buf[:, 0:3] = film["color"].view(-1, 3)[self.mine]
+        buf[:, 3] = film["alpha"].view(-1)[self.mine]
+        buf[:, 4:7] = film["background"].view(-1, 3)[self.mine]
+        buf[:, 7:10] = film["normal"].view(-1, 3)[self.mine]
         return buf
 
     def gather(self, film, group=None):
-        """One collective: every rank sends its packed pixels to rank 0, which scatters them into the
-        full raster (returned on rank 0; None elsewhere)."""
-        import torch
+        """One exchange per frame: ranks > 0 send their packed pixels to rank 0, which writes them into ITS film (returned on
+        rank 0, complete; None elsewhere)."""
         import torch.distributed as dist
-        buf = self.pack(film)
         if self.world == 1:
-            parts = [buf]
-        else:
-            parts = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(buf, parts, dst=0, group=group)
+            return film
         if self.rank != 0:
+            dist.send(self.pack(film), dst=0, group=group)
             return None
-        out = {"color": torch.zeros(self.n_pixels, 3, dtype=torch.float32, device=self.device),
-               "alpha": torch.zeros(self.n_pixels, dtype=torch.float32, device=self.device),
-               "background": torch.zeros(self.n_pixels, 3, dtype=torch.float32, device=self.device),
-               "normal": torch.zeros(self.n_pixels, 3, dtype=torch.float32, device=self.device)}
-        for r, part in enumerate(parts):
-            idx = self.all[r]
-            n = idx.numel()
-            out["color"][idx] = part[:n, 0:3]
-            out["alpha"][idx] = part[:n, 3]
-            out["background"][idx] = part[:n, 4:7]
-            out["normal"][idx] = part[:n, 7:10]
-        return out
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.irecv, self.recv[r], r, group) for r in range(1, self.world)])
+        for q in reqs:
+            q.wait()
+        for r in range(1, self.world):
+            idx, part = self.all[r], self.recv[r]
+            film["color"].view(-1, 3)[idx] = part[:, 0:3]
+            film["alpha"].view(-1)[idx] = part[:, 3]
+            film["background"].view(-1, 3)[idx] = part[:, 4:7]
+            film["normal"].view(-1, 3)[idx] = part[:, 7:10]
+        return film

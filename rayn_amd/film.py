@@ -195,16 +195,30 @@ class Film:
         return t.reshape(h, w, 3) if t.ndim == 2 else t.reshape(h, w)
 
     def save_to(self, write_channels, output_folder, base_name, transparent_background=False):
-        """Film::save_to (src/film.rs:205-378) — post-process after the hot path."""
+        """Film::save_to (src/film.rs:205-378) - the post-process after the hot path, arm by arm; the reference's
+        Err(String) cases raise ValueError with the same text."""
         os.makedirs(output_folder, exist_ok=True)
+        have = lambda k: k in self.channel_kinds
         for kind in write_channels:
             if kind == ChannelKind.Color:
-                bg = self.channel(ChannelKind.Background) if (ChannelKind.Background in self.channel_kinds and not transparent_background) else None
-                image.save_color(os.path.join(output_folder, f"{base_name}_color.png"), self.channel(ChannelKind.Color), bg)
-            elif kind == ChannelKind.WorldNormal:
-                image.save_normal(os.path.join(output_folder, f"{base_name}_normal.png"), self.channel(ChannelKind.WorldNormal))
-            elif kind == ChannelKind.Alpha:
-                a = self.channel(ChannelKind.Alpha)
-                image._png(os.path.join(output_folder, f"{base_name}_alpha.png"), np.ascontiguousarray(image._quant(a)[::-1, :, None]))
+                if have(ChannelKind.Color) and have(ChannelKind.Alpha) and transparent_background:
+                    img = image.color_image(self.channel(ChannelKind.Color), alpha=self.channel(ChannelKind.Alpha), transparent_background=True)
+                elif have(ChannelKind.Color) and have(ChannelKind.Background) and not transparent_background:
+                    img = image.color_image(self.channel(ChannelKind.Color), background=self.channel(ChannelKind.Background))
+                elif have(ChannelKind.Color) and not have(ChannelKind.Background) and not transparent_background:
+                    img = image.color_image(self.channel(ChannelKind.Color))
+                else:
+                    raise ValueError("Attempted to write Color channel with insufficient channels")
+                image.save(os.path.join(output_folder, f"{base_name}_color.png"), img)
             elif kind == ChannelKind.Background:
-                image.save_color(os.path.join(output_folder, f"{base_name}_background.png"), self.channel(ChannelKind.Background))
+                if not have(kind):
+                    raise ValueError("Attempted to write Background channel but it didn't exist")
+                image.save(os.path.join(output_folder, f"{base_name}_background.png"), image.background_image(self.channel(kind)))
+            elif kind == ChannelKind.WorldNormal:
+                if not have(kind):
+                    raise ValueError("Attempted to write WorldNormal channel but it didn't exist")
+                image.save(os.path.join(output_folder, f"{base_name}_normal.png"), image.normal_image(self.channel(kind)))
+            elif kind == ChannelKind.Alpha:
+                if not have(kind):
+                    raise ValueError("Attempted to write Alpha channel but it didn't exist")
+                image.save(os.path.join(output_folder, f"{base_name}_alpha.png"), image.alpha_image(self.channel(kind)))
