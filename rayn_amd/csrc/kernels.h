@@ -24,16 +24,19 @@ struct Pool {
 
 // per-slot NEE records + the shadow-job list (see k_shade_setup)
 struct Nee {
-    float* x;      // [ns][3][cap] unoccluded contribution (Le*f)*transmission
+    float* x;      // [4][3][cap] surface samples: unoccluded contribution (Le*f)*transmission
+    float* vtr;    // [ns-4][cap] volume samples: transmission sample point -> light (x = Le * 1/(4 pi) * vtr is rebuilt by k_shade_finish)
     float* pdf;    // [ns][cap]
     float* aux;    // [ns-4][cap] volume samples: exp(-rho_t * sample distance)
     uint8_t* vis;  // [ns][cap]   HitableStore::test_occluded: 0 occluded, 1 visible, 2 SDF march pending
+    unsigned long long* vpicks; // [cap] light index of every volume sample, 4 bits each (sample 4 + k at bits 4k..4k+3)
     float* T;      // [cap]       volume transmission of the segment
+    float* t0;     // [cap]       lane-0 ray time of the packet (only written / read when a hitable is time-sequenced)
     float* nthr;   // [3][cap]    throughput of the spawned ray
     uint8_t* flags; // [cap]      bit0 alive, bit1 surface NEE, bit2 volume NEE
     size_t cap;
     uint32_t* job_ref; // [jobcap] dense list of pending [sample*cap + slot] indices (k_shadow_list)
-    float4* job_geo;   // [jobcap][2] pending shadow segments (start.xyz, end.x | end.yz, -, -) at [sample*cap + slot]
+    float2* job_geo;   // [jobcap][3] pending shadow segments (start.xy | start.z, end.x | end.yz) at [sample*cap + slot]: 24 B
     size_t jobcap;
 };
 
@@ -97,10 +100,11 @@ struct Tables {
                           const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total, \
                           uint32_t* tile_valid, uint32_t* tile_cls_cnt);                            \
     void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base, \
-                            uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage);                    \
+                            uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt, \
+                            uint32_t* tile_cls_base);                                               \
     void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base, \
                             const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles, \
-                            const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const DCtl* ctl); \
+                            const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const uint32_t* tile_cls_base, const DCtl* ctl); \
     void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq, \
                       uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, DCtl* ctl, \
                       unsigned long long* evals, ShadeHooks hooks, const Tuning& tun);              \

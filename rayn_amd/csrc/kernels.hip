@@ -338,18 +338,30 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
+constexpr uint32_t QUEUE_UNROLL = 4; // groups a wave of a queue-streaming kernel has in flight per trip
+
 // per-group object histogram of the extend results (input of the bin scan)
 __global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8_t* __restrict__ ent_obj, const DCtl* __restrict__ ctl,
                                                      uint8_t* __restrict__ grp_cnt) {
+    // These streaming kernels are LATENCY-bound when a wave has one load in flight (r1: 0.5 TB/s): every wave takes QUEUE_UNROLL
+    // consecutive-in-stride groups per trip and issues all their loads before using any.
     const uint32_t n_entries = ctl->q_groups << 6, lane = lane_id();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += gridDim.x * blockDim.x) { // whole waves: n_entries % 64 == 0
-        const uint32_t obj = ent_obj[i], g = i >> 6;
-        uint32_t mine = 0;
-        for (uint32_t c = 0; c < nclass; c++) {
-            const uint32_t cnt = (uint32_t)__popcll(__ballot(obj == c));
-            if (lane == c) mine = cnt;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_entries; i0 += stride * QUEUE_UNROLL) { // whole waves: n_entries % 64 == 0
+        uint32_t obj[QUEUE_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) { const uint32_t i = i0 + u * stride; obj[u] = i < n_entries ? ent_obj[i] : OBJ_NONE; }
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
+            const uint32_t i = i0 + u * stride;
+            if (i >= n_entries) break; // wave-uniform
+            uint32_t mine = 0;
+            for (uint32_t c = 0; c < nclass; c++) {
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(obj[u] == c));
+                if (lane == c) mine = cnt;
+            }
+            if (lane < nclass) grp_cnt[(i >> 6) * SCAN_NC_BIN + lane] = (uint8_t)mine; // one store of nclass bytes per group
         }
-        if (lane < nclass) grp_cnt[g * SCAN_NC_BIN + lane] = (uint8_t)mine; // one store of nclass bytes per group
     }
 }
 
@@ -390,42 +402,49 @@ __global__ void __launch_bounds__(256) k_scan_tile(uint32_t nclass, uint32_t str
                                                     uint32_t* __restrict__ grp_base, uint32_t* __restrict__ grp_tile,
                                                     uint32_t* __restrict__ tile_total, uint32_t* __restrict__ tile_valid,
                                                     uint32_t* __restrict__ tile_cls_cnt) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_run[SCAN_NC_BIN];
-    __shared__ uint32_t s_off[SCAN_NC_BIN];
+    // Each WAVE owns whole classes (c = wave, wave + 4, ..) and walks the tile's groups 64 at a time with a wave scan and a
+    // scalar running total: no block barrier inside the walk (the block-wide version spent its time in __syncthreads).
+    // grp_base stays CLASS-relative; the class offsets are added by the scatter through tile_cls_base (k_tile_prefix).
+    __shared__ uint32_t s_tot[SCAN_NC_BIN];
     const uint32_t k = blockIdx.x;
     const uint32_t gb = tile_grp_begin[k], gc = tile_grp_count[k];
-    if (threadIdx.x < SCAN_NC_BIN) s_run[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < gc; base += 256) {
-        const uint32_t gi = base + threadIdx.x;
-        const bool in = gi < gc;
-        const uint32_t g = gb + gi;
-        if (in) grp_tile[g] = k;
-        for (uint32_t c = 0; c < nclass; c++) {
-            uint32_t v = in ? grp_cnt[g * stride + c] : 0u;
-            uint32_t tot;
-            uint32_t ex = block_excl_scan(v, s_wave, &tot);
-            if (in) grp_base[g * stride + c] = s_run[c] + ex; // class-relative for now
-            __syncthreads();
-            if (threadIdx.x == 0) s_run[c] += tot;
-            __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t gi = threadIdx.x; gi < gc; gi += 256) grp_tile[gb + gi] = k;
+    for (uint32_t c = wave; c < nclass; c += 4) {
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < gc; base += 64 * QUEUE_UNROLL) {
+            uint32_t v[QUEUE_UNROLL];
+#pragma unroll
+            for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
+                const uint32_t gi = base + u * 64 + lane;
+                v[u] = gi < gc ? grp_cnt[(size_t)(gb + gi) * stride + c] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
+                const uint32_t gi = base + u * 64 + lane;
+                uint32_t inc = v[u];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t n = __shfl_up(inc, off);
+                    if (lane >= (uint32_t)off) inc += n;
+                }
+                if (gi < gc) grp_base[(size_t)(gb + gi) * stride + c] = run + inc - v[u];
+                run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
         }
+        if (lane == 0) s_tot[c] = run;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t off = 0, valid = 0;
         for (uint32_t c = 0; c < nclass; c++) {
-            s_off[c] = off;
-            valid += s_run[c];
-            tile_cls_cnt[k * SCAN_NC_BIN + c] = s_run[c];
-            off += (s_run[c] + pad - 1) / pad * pad;
+            valid += s_tot[c];
+            tile_cls_cnt[k * SCAN_NC_BIN + c] = s_tot[c];
+            off += (s_tot[c] + pad - 1) / pad * pad;
         }
         tile_total[k] = off;
         tile_valid[k] = valid;
     }
-    __syncthreads();
-    for (uint32_t gi = threadIdx.x; gi < gc; gi += 256)
-        for (uint32_t c = 0; c < nclass; c++) grp_base[(gb + gi) * stride + c] += s_off[c];
 }
 
 // prefix over the tiles of the batch: where each tile's (64-padded) output segment starts.  The totals (output groups,
@@ -434,7 +453,8 @@ __global__ void __launch_bounds__(256) k_scan_tile(uint32_t nclass, uint32_t str
 __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const uint32_t* __restrict__ tile_total,
                                                        const uint32_t* __restrict__ tile_valid, uint32_t* __restrict__ tile_out_base,
                                                        uint32_t* __restrict__ out_grp_begin, uint32_t* __restrict__ out_grp_count,
-                                                       DCtl* __restrict__ ctl, int stage) {
+                                                       DCtl* __restrict__ ctl, int stage, uint32_t nclass, uint32_t pad,
+                                                       const uint32_t* __restrict__ tile_cls_cnt, uint32_t* __restrict__ tile_cls_base) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_vsum[16];
     __shared__ uint32_t s_run, s_valid;
@@ -469,6 +489,12 @@ __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const ui
             out_grp_begin[k] = begin;
             out_grp_count[k] = groups;
             tile_out_base[k] = begin * 64u;
+            uint32_t off = begin * 64u; // where each class bin of the tile starts (bins padded to 'pad' slots)
+            for (uint32_t c = 0; c < nclass; c++) {
+                tile_cls_base[k * SCAN_NC_BIN + c] = off;
+                const uint32_t cnt = tile_cls_cnt[k * SCAN_NC_BIN + c];
+                off += (cnt + pad - 1) / pad * pad;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) { s_run = run + tot; s_valid += vtot; }
@@ -514,20 +540,37 @@ __global__ void __launch_bounds__(256) k_bin_scatter(uint32_t nclass, const uint
                                                       const uint32_t* __restrict__ grp_base, const uint32_t* __restrict__ grp_tile,
                                                       const uint32_t* __restrict__ tile_out_base, const DCtl* __restrict__ ctl,
                                                       uint32_t* __restrict__ bq, uint32_t n_tiles, const uint32_t* __restrict__ tile_cls_cnt,
-                                                      const uint32_t* __restrict__ tile_total) {
+                                                      const uint32_t* __restrict__ tile_total, const uint32_t* __restrict__ tile_cls_base) {
     write_tile_padding(n_tiles, nclass, 4, tile_cls_cnt, tile_total, tile_out_base, bq);
     const uint32_t n_entries = ctl->q_groups << 6;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += gridDim.x * blockDim.x) {
-        const uint32_t g = i >> 6;
-        const uint32_t obj = ent_obj[i];
-        uint32_t rank = 0;
-        for (uint32_t c = 0; c < nclass; c++) {
-            uint64_t m = __ballot(obj == c);
-            if (obj == c) rank = mbcnt(m);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_entries; i0 += stride * QUEUE_UNROLL) {
+        uint32_t obj[QUEUE_UNROLL], ref[QUEUE_UNROLL], tbase[QUEUE_UNROLL], gbase[QUEUE_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) { // first wave of loads: object, queue entry, tile of the group
+            const uint32_t i = i0 + u * stride;
+            const bool in = i < n_entries;
+            obj[u] = in ? ent_obj[i] : OBJ_NONE;
+            ref[u] = in ? q[i] : INVALID;
+            tbase[u] = in ? grp_tile[i >> 6] : 0u;
         }
-        if (obj == OBJ_NONE) continue;
-        const uint32_t dst = tile_out_base[grp_tile[g]] + grp_base[g * SCAN_NC_BIN + obj] + rank;
-        bq[dst] = q[i];
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) { // second wave: the two dependent lookups
+            const uint32_t i = i0 + u * stride;
+            const bool live = obj[u] != OBJ_NONE;
+            gbase[u] = live ? grp_base[(i >> 6) * SCAN_NC_BIN + obj[u]] : 0u;
+            tbase[u] = live ? tile_cls_base[tbase[u] * SCAN_NC_BIN + obj[u]] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
+            if (i0 + u * stride >= n_entries) break; // wave-uniform
+            uint32_t rank = 0;
+            for (uint32_t c = 0; c < nclass; c++) {
+                uint64_t m = __ballot(obj[u] == c);
+                if (obj[u] == c) rank = mbcnt(m);
+            }
+            if (obj[u] != OBJ_NONE) bq[tbase[u] + gbase[u] + rank] = ref[u];
+        }
     }
 }
 
@@ -538,12 +581,26 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
                                                           uint32_t* __restrict__ qn, uint32_t n_tiles, const uint32_t* __restrict__ tile_total) {
     write_tile_padding(n_tiles, 1, 1, nullptr, tile_total, tile_out_base, qn);
     const uint32_t n_slots = ctl->b_groups << 6;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_slots; j += gridDim.x * blockDim.x) {
-        const uint32_t g = j >> 6;
-        const bool a = alive[j] != 0;
-        const uint32_t rank = mbcnt(__ballot(a));
-        if (!a) continue;
-        qn[tile_out_base[grp_tile[g]] + grp_base[g] + rank] = bq[j];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j0 = blockIdx.x * blockDim.x + threadIdx.x; j0 < n_slots; j0 += stride * QUEUE_UNROLL) {
+        uint32_t a[QUEUE_UNROLL], ref[QUEUE_UNROLL], tbase[QUEUE_UNROLL], gbase[QUEUE_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
+            const uint32_t j = j0 + u * stride;
+            const bool in = j < n_slots;
+            a[u] = in ? alive[j] : 0u;
+            ref[u] = in ? bq[j] : INVALID;
+            tbase[u] = in ? grp_tile[j >> 6] : 0u;
+            gbase[u] = in ? grp_base[j >> 6] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) tbase[u] = a[u] ? tile_out_base[tbase[u]] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
+            if (j0 + u * stride >= n_slots) break; // wave-uniform
+            const uint32_t rank = mbcnt(__ballot(a[u] != 0));
+            if (a[u]) qn[tbase[u] + gbase[u] + rank] = ref[u];
+        }
     }
 }
 
@@ -628,9 +685,10 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     // job_geo[2*(s*cap + slot)..]; k_shadow_list collects the pending (sample, slot) pairs.  (A compacted job list would need
     // one atomic per wave per sample on a single counter - that alone cost 0.5 s per frame.)
     auto park_job = [&](uint32_t s, f3 a, f3 b) {
-        const size_t idx = s * cap + j; // 32 contiguous bytes per segment: one or two HBM sectors per fetch
-        nee.job_geo[2 * idx] = make_float4(a.x, a.y, a.z, b.x);
-        nee.job_geo[2 * idx + 1] = make_float4(b.y, b.z, t0, 0.0f); // t0: the packet time a moving TracedSDF is sampled at
+        const size_t idx = s * cap + j; // 24 contiguous bytes per segment (the packet time of a moving SDF is per slot: nee.t0)
+        nee.job_geo[3 * idx] = make_float2(a.x, a.y);
+        nee.job_geo[3 * idx + 1] = make_float2(a.z, b.x);
+        nee.job_geo[3 * idx + 2] = make_float2(b.y, b.z);
     };
     // analytic spheres of test_occluded (every factor is exactly 0 or 1 -> order independent)
     auto spheres_visible = [&](f3 a, f3 b) {
@@ -754,8 +812,8 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
                     float dl = mag(end_point - sp);
                     float f = 1.0f / (4.0f * PI_F);
                     float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dl) : 1.0f;
-                    f3 x = L.emission * f * tr;
-                    nee.x[(s * 3 + 0) * cap + j] = x.x; nee.x[(s * 3 + 1) * cap + j] = x.y; nee.x[(s * 3 + 2) * cap + j] = x.z;
+                    (void)f; // x = L.emission * f * tr is rebuilt by k_shade_finish from the light index and tr (same operations, same bits)
+                    nee.vtr[(s - 4) * cap + j] = tr;
                     nee.pdf[s * cap + j] = vpdf * lpdf;
                     nee.aux[(s - 4) * cap + j] = vaux;
                     uint8_t vis = 1;
@@ -766,6 +824,8 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
             }
         }
     }
+    if (do_vol) nee.vpicks[j] = vol_picks;
+    if (sc.anim_spheres) nee.t0[j] = t0;
     // ---- BSDF sample, roulette, AOVs, termination (src/integrator.rs:134-203)
     if (valid) {
         if (receives) {
@@ -814,7 +874,10 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
 // single counter saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue") and every (wave, group) writes its refs
 // densely in lane order - coalesced 256-byte stores, and consecutive list entries point at consecutive segments, which
 // keeps the shadow kernel's fetch contiguous.  List order is irrelevant to the result: it is written back by index.
-constexpr uint32_t SCAN_ITEMS = 16;
+#ifndef RAYN_SCAN_ITEMS
+#define RAYN_SCAN_ITEMS 16
+#endif
+constexpr uint32_t SCAN_ITEMS = RAYN_SCAN_ITEMS;
 __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, DCtl* __restrict__ ctl) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
@@ -904,7 +967,8 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
                 const uint32_t rank = mbcnt(need), avail = end - cur;
                 if (!has && rank < avail) {
                     ref = nee.job_ref[cur + rank]; // [sample][slot]
-                    const float4 ja = nee.job_geo[2 * (size_t)ref], jb = nee.job_geo[2 * (size_t)ref + 1];
+                    const float2 j0 = nee.job_geo[3 * (size_t)ref], j1 = nee.job_geo[3 * (size_t)ref + 1], j2 = nee.job_geo[3 * (size_t)ref + 2];
+                    const float4 ja = make_float4(j0.x, j0.y, j1.x, j1.y), jb = make_float4(j2.x, j2.y, sc.anim_spheres ? nee.t0[ref % (uint32_t)nee.cap] : 0.0f, 0.0f);
                     wa = f3{ja.x, ja.y, ja.z};
                     wb = f3{ja.w, jb.x, jb.y};
                     jt0 = jb.z;
@@ -980,7 +1044,8 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                 const uint32_t rank = mbcnt(need), avail = end - cur;
                 if ((need >> lane) & 1ull) if (rank < avail) {
                     n_ref = nee.job_ref[cur + rank];
-                    const float4 ja = nee.job_geo[2 * (size_t)n_ref], jb = nee.job_geo[2 * (size_t)n_ref + 1];
+                    const float2 j0 = nee.job_geo[3 * (size_t)n_ref], j1 = nee.job_geo[3 * (size_t)n_ref + 1], j2 = nee.job_geo[3 * (size_t)n_ref + 2];
+                    const float4 ja = make_float4(j0.x, j0.y, j1.x, j1.y), jb = make_float4(j2.x, j2.y, sc.anim_spheres ? nee.t0[n_ref % (uint32_t)nee.cap] : 0.0f, 0.0f);
                     const f3 origin = sphere_center(h, jb.z); // TracedSDF origin at the packet time (extension; zero in the reference)
                     n_start = f3{ja.x, ja.y, ja.z} - origin;
                     const f3 e = f3{ja.w, jb.x, jb.y} - origin;
@@ -1053,8 +1118,12 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
         }
         if (flags & 4u) { // src/integrator.rs:99-131
             const float corr = (float)nl / 4.0f / (float)VM;
+            const unsigned long long vpicks = nee.vpicks[j];
             for (uint32_t s = 4; s < 4 + 4 * VM; s++) {
-                const f3 x = f3{nee.x[(s * 3 + 0) * cap + j], nee.x[(s * 3 + 1) * cap + j], nee.x[(s * 3 + 2) * cap + j]};
+                // volume_sample_one_light's li * f * transmission (src/integrator.rs:269-279): f = 1/(4 pi) is a constant and
+                // k_shade_setup kept the transmittance, so x is rebuilt here with the same two multiplies
+                const float f = 1.0f / (4.0f * PI_F);
+                const f3 x = sc.l[(uint32_t)(vpicks >> (4 * (s - 4))) & 15u].emission * f * nee.vtr[(s - 4) * cap + j];
                 const float occ = (float)nee.vis[s * cap + j];
                 const f3 li = x * occ / nee.pdf[s * cap + j];
                 rad = rad + li * thr * corr * sc.rho_s * nee.aux[(s - 4) * cap + j];
@@ -1222,6 +1291,173 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_resolve for spp <= 1024: the same replay of the reference's add order, with the sort REGISTER-resident.  One wave per
+// pixel holds KPL = n_sort / 64 keys per lane.  Bitonic steps whose partner lies in the same lane are compare-exchanges
+// between registers; the others exchange register r with lane ^ (jj / KPL) through a wave shuffle - no LDS round trip and no
+// barrier per step (the LDS version spent 55 x 8 dependent LDS round trips per sort at 1024 spp: 0.9 TB/s, 11 % of the HBM roof).
+// LDS only stages the sorted samples for the three serial-sum lanes.
+// ------------------------------------------------------------------------------------------------
+RD unsigned long long shfl_xor_key(unsigned long long v, uint32_t m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, (int)m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), (int)m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+RD uint32_t shfl_xor_key(uint32_t v, uint32_t m) { return (uint32_t)__shfl_xor((int)v, (int)m); }
+
+// ascending bitonic sort of 64 * KPL keys, element e = lane * KPL + r
+template <typename K, uint32_t KPL>
+RD void bitonic_sort_reg(K (&key)[KPL]) {
+    const uint32_t lane = lane_id();
+    constexpr uint32_t N = 64 * KPL;
+#pragma unroll
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+            if (jj < KPL) { // partner in the same lane: registers r and r | jj
+#pragma unroll
+                for (uint32_t r = 0; r < KPL; r++) {
+                    if ((r & jj) == 0) {
+                        const bool asc = k < KPL ? (r & k) == 0 : ((lane * KPL) & k) == 0;
+                        const K a = key[r], b = key[r | jj];
+                        const bool sw = (a > b) == asc;
+                        key[r] = sw ? b : a;
+                        key[r | jj] = sw ? a : b;
+                    }
+                }
+            } else { // partner = the same register of lane ^ (jj / KPL)
+                const uint32_t lm = jj / KPL;
+                const bool keep_min = (((lane * KPL) & k) == 0) == ((lane & lm) == 0);
+#pragma unroll
+                for (uint32_t r = 0; r < KPL; r++) {
+                    const K o = shfl_xor_key(key[r], lm);
+                    const bool take = keep_min ? o < key[r] : o > key[r];
+                    key[r] = take ? o : key[r];
+                }
+            }
+        }
+    }
+}
+
+// keys loaded sample-major (register r of lane l = sample r * 64 + l): true when they are already in non-decreasing sample order
+RD unsigned long long shfl_key(unsigned long long v, uint32_t src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+RD uint32_t shfl_key(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); }
+template <typename K, uint32_t KPL>
+RD bool is_sorted_reg(const K (&key)[KPL]) {
+    const uint32_t lane = lane_id();
+    bool ok = true;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) {
+        // successor of sample r * 64 + lane: lane + 1 of the same register, or lane 0 of the next register (none after the last)
+        const K same = shfl_key(key[r], (lane + 1) & 63u);
+        const K wrap = r + 1 < KPL ? shfl_key(key[r + 1 < KPL ? r + 1 : r], 0u) : (K)~(K)0;
+        ok = ok && !(key[r] > (lane == 63 ? wrap : same));
+    }
+    return __ballot(!ok) == 0;
+}
+
+template <uint32_t KPL>
+__global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
+                                                     float* __restrict__ out_color, float* __restrict__ out_alpha,
+                                                     float* __restrict__ out_background, float* __restrict__ out_normal) {
+    constexpr uint32_t n_sort = 64 * KPL;
+    __shared__ __attribute__((aligned(16))) float2 rg[n_sort]; // sorted samples: (r, g) | AOV pass: normal (x, y)
+    __shared__ __attribute__((aligned(16))) float2 bf[n_sort]; // (b, background flag)   | AOV pass: first half = normal z
+    float* nz = (float*)bf;
+    constexpr unsigned long long NOKEY = ~0ull;
+    const DScene& sc = *scp;
+    const DTile tile = tiles[blockIdx.y];
+    const uint32_t lpix = blockIdx.x;
+    if (lpix >= tile.ew * tile.eh) return;
+    const uint32_t spp = sc.spp, lane = threadIdx.x;
+    const uint32_t P0 = tile.pool_base + lpix * spp;
+    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
+    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
+    const float n = (float)spp;
+    // ---- Color / Background in (depth, slot) order: key = depth:7 | slot:32 | background:1 | sample:12
+    unsigned long long key[KPL];
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) {
+        const uint32_t i = r * 64 + lane;
+        unsigned long long k = NOKEY;
+        if (i < spp) {
+            const uint32_t info = pool.term_info[P0 + i];
+            if (info != TERM_NONE)
+                k = ((unsigned long long)(info & 0x7Fu) << 45) | ((unsigned long long)pool.term_key[P0 + i] << 13) | ((info >> 7) << 12) | i;
+        }
+        key[r] = k;
+    }
+    const bool sorted = is_sorted_reg<unsigned long long, KPL>(key); // sky-only pixels arrive sorted (sample-major layout)
+    if (!sorted) bitonic_sort_reg<unsigned long long, KPL>(key);   // now element lane * KPL + r
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) cnt += (uint32_t)__popcll(__ballot(key[r] != NOKEY));
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) {
+        if (key[r] != NOKEY) {
+            const uint32_t e = sorted ? r * 64 + lane : lane * KPL + r, lo = (uint32_t)key[r];
+            const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
+            rg[e] = make_float2(c.x, c.y);
+            bf[e] = make_float2(c.z, __uint_as_float((lo >> 12) & 1u));
+        }
+    }
+    __syncthreads();
+    if (lane < 3) {
+        const float* src = lane < 2 ? (const float*)rg + lane : (const float*)bf; // stride 2 floats
+        const uint32_t* flg = (const uint32_t*)bf + 1;
+        float c = 0.0f, b = 0.0f;
+        uint32_t e = 0;
+        for (; e + 8 <= cnt; e += 8) {
+            float v[8];
+            uint32_t f[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const bool bg = f[u] != 0;
+                const float s = (bg ? b : c) + v[u];
+                b = bg ? s : b;
+                c = bg ? c : s;
+            }
+        }
+        for (; e < cnt; e++) {
+            if (flg[2 * e]) b += src[2 * e]; else c += src[2 * e];
+        }
+        out_color[3 * fi + lane] = c / n;
+        out_background[3 * fi + lane] = b / n;
+    }
+    __syncthreads();
+    // ---- Alpha / WorldNormal: depth-0 packets are object-major, then queue (= sample) order: key = object:16 | sample:16
+    uint32_t k32[KPL];
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) {
+        const uint32_t i = r * 64 + lane;
+        uint32_t k = INVALID;
+        if (i < spp) { const uint32_t ob = __float_as_uint(pool.aov[P0 + i].w); if (ob != OBJ_NONE) k = (ob << 16) | i; }
+        k32[r] = k;
+    }
+    const bool sorted0 = is_sorted_reg<uint32_t, KPL>(k32); // the common case: one object per pixel
+    if (!sorted0) bitonic_sort_reg<uint32_t, KPL>(k32);
+    uint32_t cnt0 = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) cnt0 += (uint32_t)__popcll(__ballot(k32[r] != INVALID));
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++)
+        if (k32[r] != INVALID) {
+            const uint32_t e = sorted0 ? r * 64 + lane : lane * KPL + r;
+            const float4 a = pool.aov[P0 + (k32[r] & 0xFFFFu)];
+            rg[e] = make_float2(a.x, a.y);
+            nz[e] = a.z;
+        }
+    __syncthreads();
+    // Alpha adds 1.0 per depth-0 surface sample: every partial sum is an integer < 2^24, so the serial sum is the count
+    if (lane == 3) out_alpha[fi] = (float)cnt0 / n;
+    else if (lane < 2) out_normal[3 * fi + lane] = serial_sum((const float*)rg + lane, 2, cnt0) / n;
+    else if (lane == 2) out_normal[3 * fi + 2] = serial_sum(nz, 1, cnt0) / n;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Multi-device film assembly (no reference counterpart; tiles are independent, src/film.rs:439-627): a device packs the
 // pixels of the tiles it rendered into one contiguous buffer (10 floats per pixel: Color 3 | Alpha 1 | Background 3 |
 // WorldNormal 3, tile after tile, pixel-major inside a tile like the path pool), the buffer crosses xGMI with ONE peer copy,
@@ -1355,14 +1591,16 @@ void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t
     hipLaunchKernelGGL(k_scan_tile, dim3(n_tiles), dim3(256), 0, s, nclass, stride, pad, grp_cnt, tgb, tgc, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt);
 }
 void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
-                        uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage) {
-    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, s, n_tiles, tile_total, tile_valid, tile_out_base, ogb, ogc, ctl, stage);
+                        uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt,
+                        uint32_t* tile_cls_base) {
+    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, s, n_tiles, tile_total, tile_valid, tile_out_base, ogb, ogc, ctl, stage, nclass, pad, tile_cls_cnt,
+                       tile_cls_base);
 }
 void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
                         const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles,
-                        const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const DCtl* ctl) {
+                        const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const uint32_t* tile_cls_base, const DCtl* ctl) {
     hipLaunchKernelGGL(k_bin_scatter, stride_grid(max_entries, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, q, ent_obj, grp_base, grp_tile, tile_out_base, ctl, bq,
-                       n_tiles, tile_cls_cnt, tile_total);
+                       n_tiles, tile_cls_cnt, tile_total, tile_cls_base);
 }
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
                   uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, DCtl* ctl,
@@ -1407,10 +1645,18 @@ void launch_tile_pixels(hipStream_t s, bool pack, const DTile* tiles, uint32_t n
 }
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {
+    const dim3 grid(max_tile_pixels, n_tiles);
+    if (spp <= 1024) { // register-resident sort, one wave per pixel
+        if (spp <= 64) hipLaunchKernelGGL(k_resolve_reg<1>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        else if (spp <= 128) hipLaunchKernelGGL(k_resolve_reg<2>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        else if (spp <= 256) hipLaunchKernelGGL(k_resolve_reg<4>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        else if (spp <= 512) hipLaunchKernelGGL(k_resolve_reg<8>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        else hipLaunchKernelGGL(k_resolve_reg<16>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        return;
+    }
     uint32_t n_sort = 8;
     while (n_sort < spp) n_sort <<= 1;
-    hipLaunchKernelGGL(k_resolve, dim3(max_tile_pixels, n_tiles), dim3(64), n_sort * 16, s, sc, tiles, pool, out_color, out_alpha, out_background,
-                       out_normal, n_sort);
+    hipLaunchKernelGGL(k_resolve, grid, dim3(64), n_sort * 16, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal, n_sort);
 }
 void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {
     hipLaunchKernelGGL(k_probe_dist, grid_for(n, 256), dim3(256), 0, s, sc, hit_index, pts, out, n);

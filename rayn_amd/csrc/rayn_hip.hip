@@ -330,9 +330,10 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     acc(BG, 1); acc(BG, 4); acc(BG, 4);                                                            // bgrp_*
     acc(total_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                         // tiles of every batch, pgrp_tile
     for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
-    acc(max_tiles * SCAN_NC_BIN, 4); acc(1, sizeof(DCtl));                                         // tile_cls_cnt, control block
-    acc(NS * 3 * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);
-    acc(JOBCAP, 4); acc(2 * JOBCAP, 16);
+    acc(max_tiles * SCAN_NC_BIN, 4); acc(max_tiles * SCAN_NC_BIN, 4); acc(1, sizeof(DCtl));        // tile_cls_cnt, tile_cls_base, control block
+    acc(12 * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 8); // x, vtr, pdf, aux, vis, vpicks
+    acc(BCAP, 4); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);                                                                    // T, t0, nthr, flags
+    acc(JOBCAP, 4); acc(3 * JOBCAP, 8);
     if (need > w->arena.cap) {
         if (w->arena.base) WCHK(hipFree(w->arena.base));
         w->arena.base = nullptr; w->arena.cap = 0;
@@ -353,13 +354,14 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     uint32_t* tgbA = A.take<uint32_t>(max_tiles); uint32_t* tgcA = A.take<uint32_t>(max_tiles);
     uint32_t* tgbB = A.take<uint32_t>(max_tiles); uint32_t* tgcB = A.take<uint32_t>(max_tiles);
     uint32_t* tile_total = A.take<uint32_t>(max_tiles); uint32_t* tile_valid = A.take<uint32_t>(max_tiles); uint32_t* tile_out_base = A.take<uint32_t>(max_tiles);
-    uint32_t* tile_cls_cnt = A.take<uint32_t>(max_tiles * SCAN_NC_BIN);
+    uint32_t* tile_cls_cnt = A.take<uint32_t>(max_tiles * SCAN_NC_BIN); uint32_t* tile_cls_base = A.take<uint32_t>(max_tiles * SCAN_NC_BIN);
     DCtl* d_ctl = A.take<DCtl>(1);
     Nee nee;
     nee.cap = BCAP; nee.jobcap = JOBCAP;
-    nee.x = A.take<float>(NS * 3 * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
-    nee.vis = A.take<uint8_t>(NS * BCAP); nee.T = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
-    nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float4>(2 * JOBCAP);
+    nee.x = A.take<float>(12 * BCAP); nee.vtr = A.take<float>((NS - 4 + 1) * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
+    nee.vis = A.take<uint8_t>(NS * BCAP); nee.vpicks = A.take<unsigned long long>(BCAP);
+    nee.T = A.take<float>(BCAP); nee.t0 = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
+    nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float2>(3 * JOBCAP);
     if (A.off > A.cap) return wfail(w, RAYN_ERR_OOM, "internal: arena under-sized");
 
     // The whole share is ENQUEUED without a single host<->device round trip: queue sizes live in d_ctl, the tile lists of all
@@ -404,8 +406,8 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
             {
                 Timed t(w, prof, PC_BIN);
                 K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0);
-                K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, max_entries, bq, nt, tile_cls_cnt, tile_total, d_ctl);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0, hs.n_hitables, 4, tile_cls_cnt, tile_cls_base);
+                K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, max_entries, bq, nt, tile_cls_cnt, tile_total, tile_cls_base, d_ctl);
             }
             if (ctx->trace_tile >= 0) { // diagnostics only (synchronises): packet order of one tile, in HitStore::process_hits order
                 WCHK(hipStreamSynchronize(stream));
@@ -449,7 +451,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
             {
                 Timed t(w, prof, PC_COMPACT);
                 K.scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid, tile_cls_cnt);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_ctl, 1);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_ctl, 1, 1, 1, tile_cls_cnt, tile_cls_base);
                 K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, max_slots, qnext, nt, tile_total, d_ctl);
             }
             std::swap(qcur, qnext);
@@ -537,7 +539,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         for (const Worker& w : ctx->workers) free_b += w.arena.cap;
-        const size_t per_path = 101 + 53 * (size_t)F.NS + 4 * ((size_t)F.NS - 3) + 17; // pool + queues + NEE records + shadow segments
+        const size_t per_path = 118 + 81 + 33 * (size_t)F.NS + 8 * ((size_t)F.NS - 3); // pool + queues | NEE records: fixed part, per light sample (pdf, vis, job ref, 24-B segment), per volume sample (vtr, aux)
         const size_t budget_paths = (size_t)(0.6 * (double)free_b) / per_path;
         const int max_w = std::min(std::min(ctx->n_workers, MAX_WORKERS), (int)std::min<size_t>(owned.size(), MAX_WORKERS));
         for (int c = std::max(max_w, 1); c >= 1; c--) {

@@ -1,7 +1,7 @@
 """Per-kernel-class times of ONE rank's share of a bench workload.
 usage: share_profile.py <tile_first> <tile_step> [workload=c2]"""
-import sys, time
-sys.path.insert(0, '.')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rayn_amd
 from rayn_amd import setup as S
 from bench import WORKLOADS
