@@ -245,6 +245,16 @@ class Film {
         const size_t n = (size_t)res.w * res.h;
         color.assign(3 * n, 0.0f); alpha.assign(n, 0.0f); background.assign(3 * n, 0.0f); world_normal.assign(3 * n, 0.0f);
     }
+    // the same film rendered by several GPUs of this process (rayn_hip_create_multi: tiles dealt in rotation, one peer copy per GPU)
+    Film(const std::vector<ChannelKind>& channels, Extent2u res, const std::vector<int>& devices) : kinds_(channels), res_(res) {
+        for (size_t i = 0; i < channels.size(); i++)
+            for (size_t j = i + 1; j < channels.size(); j++)
+                if (channels[i] == channels[j]) throw std::invalid_argument("Attempted to create multiple channels of one kind");
+        int rc = rayn_hip_create_multi(devices.data(), (int)devices.size(), &ctx_);
+        if (rc != RAYN_OK) throw std::runtime_error("rayn_hip_create_multi failed: " + std::to_string(rc) + " (no GPU? there is no CPU fallback)");
+        const size_t n = (size_t)res.w * res.h;
+        color.assign(3 * n, 0.0f); alpha.assign(n, 0.0f); background.assign(3 * n, 0.0f); world_normal.assign(3 * n, 0.0f);
+    }
     ~Film() { if (ctx_) rayn_hip_destroy(ctx_); }
     Film(const Film&) = delete;
     Film& operator=(const Film&) = delete;

@@ -73,6 +73,8 @@ struct Tuning {
     uint32_t prefetch_min_shadow = 32;
     uint32_t ablate = 0;                  // timing-only debug mask for k_shade_setup (see the kernel)
     bool fast_path = true;                // single-SDF specialisations k_extend1 / k_shadow1
+    bool shadow_scan = false;             // k_shadow1 finds the pending segments itself instead of consuming k_shadow_list's job list; measured
+                                          // SLOWER (c3 1/8 share: 935.8 ms vs 907.2 + 17.3 for the list; c2: 100.8 vs 96.5 ms) - kept as an option
     bool setup_stride = false;            // k_shade_setup as a grid-stride loop (true) or one slot per thread over the upper-bound grid
 };
 

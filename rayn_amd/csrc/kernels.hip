@@ -1006,14 +1006,28 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
 
 // Fast path of k_shadow for scenes with exactly one TracedSDF: uniform SDF parameters, and a
 // prefetched NEXT segment per lane (see k_extend1).
-template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, DCtl* __restrict__ ctl,
+// SCAN (Tuning::shadow_scan, OFF by default - measured 1-4 % slower than list + march, the window logic and its 8 extra VGPRs
+// cost the hot loop more than the separate pass): the kernel finds its jobs itself.  Instead of consuming the dense list
+// k_shadow_list builds (one more pass over all NS x n_slots visibility bytes + 4 B per job written and read back: 1.4 % of a
+// config-3 frame), a wave walks the (sample, slot)
+// id space in 64-id windows: one coalesced load of the visibility bytes, a ballot of the pending ones, and the lanes that
+// need a segment take the window's pending ids in order - the k-th needy lane gets the k-th pending id, matched through a
+// 64-entry LDS table indexed by rank (one ds_write + one ds_read per window).  Ids are handed out in chunks like list
+// entries were; results are written by id, so nothing depends on which lane marches which segment.
+template <bool COUNT, bool SCAN>
+__global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, DCtl* __restrict__ ctl, uint32_t ns,
                                                   uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
+    __shared__ uint32_t s_pick[4][64];
     const DScene& sc = *scp;
-    const uint32_t lane = lane_id();
-    const uint32_t n_jobs = ctl->job_count, max_vis = sc.max_vis_marches;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t n_slots = ctl->b_groups << 6;
+    const uint32_t n_jobs = SCAN ? ns * n_slots : ctl->job_count, max_vis = sc.max_vis_marches; // SCAN: ids, not jobs
     uint32_t* const head = &ctl->head_shadow;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
+    if (!SCAN && blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
+    // SCAN: the current 64-id window (wave-uniform): pending ids not handed out yet, and the [sample*cap + slot] ref of its id 0
+    uint64_t win_mask = 0;
+    uint32_t win_ref = 0, win_s = 0, win_off = 0, taken = 0;
+    (void)s_pick; (void)wave; (void)win_ref; (void)win_s; (void)win_off; (void)taken;
     const DHitable h = sc.h[ks];
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
@@ -1032,7 +1046,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             for (;;) {
                 const uint64_t need = endgame ? __ballot(!n_has && !c_has) : __ballot(!n_has);
                 if (need == 0) break;
-                if (cur == end) {
+                if (cur == end && (!SCAN || win_mask == 0)) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(head, CHUNK);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -1040,10 +1054,30 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                     cur = base;
                     end = min(base + CHUNK, n_jobs);
                     endgame = n_jobs - base < ENDGAME_ENTRIES;
+                    if (SCAN) { win_s = base / n_slots; win_off = base - win_s * n_slots; } // one division per chunk of 256 ids
                 }
-                const uint32_t rank = mbcnt(need), avail = end - cur;
-                if ((need >> lane) & 1ull) if (rank < avail) {
-                    n_ref = nee.job_ref[cur + rank];
+                uint32_t rank = mbcnt(need), avail = end - cur;
+                bool take = ((need >> lane) & 1ull) && rank < avail;
+                if (SCAN) {
+                    if (win_mask == 0) { // next 64-id window of the chunk (n_slots % 64 == 0: a window never straddles samples)
+                        win_ref = (uint32_t)(win_s * nee.cap) + win_off;
+                        win_mask = __ballot(nee.vis[win_ref + lane] == 2);
+                        cur += 64; win_off += 64;
+                        if (win_off == n_slots) { win_off = 0; win_s++; }
+                        if (win_mask == 0) continue;
+                    }
+                    const uint32_t n_serve = min((uint32_t)__popcll(need), (uint32_t)__popcll(win_mask));
+                    const uint32_t prank = mbcnt(win_mask);
+                    const bool give = ((win_mask >> lane) & 1ull) && prank < n_serve;
+                    if (give) s_pick[wave][prank] = lane;
+                    __builtin_amdgcn_wave_barrier(); // same wave: LDS operations complete in order, keep the compiler from reordering
+                    take = ((need >> lane) & 1ull) && rank < n_serve;
+                    if (take) n_ref = win_ref + s_pick[wave][rank];
+                    __builtin_amdgcn_wave_barrier();
+                    win_mask &= ~__ballot(give);
+                    taken += n_serve;
+                } else if (take) n_ref = nee.job_ref[cur + rank];
+                if (take) {
                     const float2 j0 = nee.job_geo[3 * (size_t)n_ref], j1 = nee.job_geo[3 * (size_t)n_ref + 1], j2 = nee.job_geo[3 * (size_t)n_ref + 2];
                     const float4 ja = make_float4(j0.x, j0.y, j1.x, j1.y), jb = make_float4(j2.x, j2.y, sc.anim_spheres ? nee.t0[n_ref % (uint32_t)nee.cap] : 0.0f, 0.0f);
                     const f3 origin = sphere_center(h, jb.z); // TracedSDF origin at the packet time (extension; zero in the reference)
@@ -1054,7 +1088,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                     n_dir = div_by_mag(n_dir, n_max);
                     n_has = true;
                 }
-                cur += min((uint32_t)__popcll(need), avail);
+                if (!SCAN) cur += min((uint32_t)__popcll(need), avail);
             }
         }
         if (!c_has && n_has) {
@@ -1087,6 +1121,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             if (res >= 0) { nee.vis[ref] = (uint8_t)res; c_has = false; }
         }
     }
+    if (SCAN && lane == 0 && taken) atomicAdd(&ctl->shadow_jobs, (unsigned long long)taken);
 #ifdef RAYN_COUNT_TRIPS
     evals = trips64;
 #endif
@@ -1255,10 +1290,11 @@ __global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, 
             for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++) {
+                // two INDEPENDENT serial chains: the accumulator a sample does not belong to adds +0.0, an exact identity here
+                // (x + 0.0 == x for every x except -0.0, and a sum that starts at +0.0 never becomes -0.0 under round-to-nearest)
                 const bool bg = f[u] != 0;
-                const float s = (bg ? b : c) + v[u];
-                b = bg ? s : b;
-                c = bg ? c : s;
+                c += bg ? 0.0f : v[u];
+                b += bg ? v[u] : 0.0f;
             }
         }
         for (; e < cnt; e++) {
@@ -1303,34 +1339,41 @@ RD unsigned long long shfl_xor_key(unsigned long long v, uint32_t m) {
 }
 RD uint32_t shfl_xor_key(uint32_t v, uint32_t m) { return (uint32_t)__shfl_xor((int)v, (int)m); }
 
-// ascending bitonic sort of 64 * KPL keys, element e = lane * KPL + r
+// ascending bitonic sort of 64 * KPL keys, element e = lane * KPL + r.  The stage (k) and the cross-lane sub-step (jj) loops
+// stay ROLLED (a fully unrolled u64 network at KPL = 16 was 70 KB of code and ran out of the instruction cache); only the
+// per-register work is unrolled, and selects are written so that no branch separates a shuffle from its use.
 template <typename K, uint32_t KPL>
 RD void bitonic_sort_reg(K (&key)[KPL]) {
     const uint32_t lane = lane_id();
     constexpr uint32_t N = 64 * KPL;
-#pragma unroll
+#pragma nounroll
     for (uint32_t k = 2; k <= N; k <<= 1) {
+        const bool asc_lane = ((lane * KPL) & k) == 0; // direction of this lane's elements when k >= KPL
+#pragma nounroll
+        for (uint32_t jj = k >> 1; jj >= KPL && jj > 0; jj >>= 1) { // partner = the same register of lane ^ (jj / KPL)
+            const uint32_t lm = jj / KPL;
+            const bool keep_min = asc_lane == ((lane & lm) == 0);
+            K o[KPL];
 #pragma unroll
-        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-            if (jj < KPL) { // partner in the same lane: registers r and r | jj
+            for (uint32_t r = 0; r < KPL; r++) o[r] = shfl_xor_key(key[r], lm);
+#pragma unroll
+            for (uint32_t r = 0; r < KPL; r++) {
+                const bool take = (o[r] < key[r]) == keep_min; // equal keys: either copy is the same value
+                key[r] = take ? o[r] : key[r];
+            }
+        }
+#pragma unroll
+        for (uint32_t jj = KPL / 2; jj > 0; jj >>= 1) { // partner in the same lane: registers r and r | jj
+            if (jj < k) {                                 // wave-uniform: this sub-step belongs to stage k
 #pragma unroll
                 for (uint32_t r = 0; r < KPL; r++) {
                     if ((r & jj) == 0) {
-                        const bool asc = k < KPL ? (r & k) == 0 : ((lane * KPL) & k) == 0;
+                        const bool asc = k < KPL ? (r & k) == 0 : asc_lane;
                         const K a = key[r], b = key[r | jj];
                         const bool sw = (a > b) == asc;
                         key[r] = sw ? b : a;
                         key[r | jj] = sw ? a : b;
                     }
-                }
-            } else { // partner = the same register of lane ^ (jj / KPL)
-                const uint32_t lm = jj / KPL;
-                const bool keep_min = (((lane * KPL) & k) == 0) == ((lane & lm) == 0);
-#pragma unroll
-                for (uint32_t r = 0; r < KPL; r++) {
-                    const K o = shfl_xor_key(key[r], lm);
-                    const bool take = keep_min ? o < key[r] : o > key[r];
-                    key[r] = take ? o : key[r];
                 }
             }
         }
@@ -1415,10 +1458,11 @@ __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ s
             for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++) {
+                // two INDEPENDENT serial chains: the accumulator a sample does not belong to adds +0.0, an exact identity here
+                // (x + 0.0 == x for every x except -0.0, and a sum that starts at +0.0 never becomes -0.0 under round-to-nearest)
                 const bool bg = f[u] != 0;
-                const float s = (bg ? b : c) + v[u];
-                b = bg ? s : b;
-                c = bg ? c : s;
+                c += bg ? 0.0f : v[u];
+                b += bg ? v[u] : 0.0f;
             }
         }
         for (; e < cnt; e++) {
@@ -1619,11 +1663,15 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
     hooks.after(0);
     if (has_sdf) {
         hooks.before(1);
-        hipLaunchKernelGGL(k_shadow_list, stride_grid(ns * max_slots, 256 * SCAN_ITEMS, STREAM_BLOCKS), dim3(256), 0, s, nee, ns, ctl);
+        const bool fast = single_sdf >= 0 && tun.fast_path, scan = fast && tun.shadow_scan;
+        if (!scan) hipLaunchKernelGGL(k_shadow_list, stride_grid(ns * max_slots, 256 * SCAN_ITEMS, STREAM_BLOCKS), dim3(256), 0, s, nee, ns, ctl);
         const dim3 grid = stride_grid(ns * max_slots, 256, tun.persistent_blocks);
-        if (single_sdf >= 0 && tun.fast_path) {
-            if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
-            else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
+        if (scan) {
+            if (count) hipLaunchKernelGGL((k_shadow1<true, true>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
+            else hipLaunchKernelGGL((k_shadow1<false, true>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
+        } else if (fast) {
+            if (count) hipLaunchKernelGGL((k_shadow1<true, false>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
+            else hipLaunchKernelGGL((k_shadow1<false, false>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
         } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
         else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
         hooks.after(1);

@@ -762,6 +762,7 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     if (const char* e = getenv("RAYN_HIP_PREFETCH_SHADOW")) ctx->tun.prefetch_min_shadow = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("RAYN_HIP_ABLATE")) ctx->tun.ablate = (uint32_t)atoi(e);
     if (const char* e = getenv("RAYN_HIP_FAST_PATH")) ctx->tun.fast_path = atoi(e) != 0;
+    if (const char* e = getenv("RAYN_HIP_SHADOW_SCAN")) ctx->tun.shadow_scan = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_SETUP_STRIDE")) ctx->tun.setup_stride = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_PERSISTENT_BLOCKS")) ctx->tun.persistent_blocks = (uint32_t)std::max(1, atoi(e));
     *out = ctx;

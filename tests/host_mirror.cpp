@@ -1,6 +1,7 @@
 // Test driver for include/rayn_host.hpp (the C++ host mirror).
 //   host_mirror desc W H volumes out.bin                -> raw rayn_world_desc of setup::setup()   (no GPU needed)
-//   host_mirror render W H SAMPLES BOUNCES volumes out.bin -> film: color(3n) alpha(n) background(3n) normal(3n) floats
+//   host_mirror render W H SAMPLES BOUNCES volumes out.bin [n_devices] -> film: color(3n) alpha(n) background(3n) normal(3n) floats
+//       n_devices > 0: a multi-device Film over n_devices entries of GPU 0 (rayn_hip_create_multi)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +26,10 @@ int main(int argc, char** argv) {
         Film dup({ChannelKind::Color, ChannelKind::Color}, Extent2u(W, H));
         return 3; // must have thrown (Film::new returns Err for duplicate kinds)
     } catch (const std::invalid_argument&) {}
-    Film film({ChannelKind::Color, ChannelKind::Alpha, ChannelKind::Background, ChannelKind::WorldNormal}, Extent2u(W, H));
+    const std::vector<ChannelKind> all = {ChannelKind::Color, ChannelKind::Alpha, ChannelKind::Background, ChannelKind::WorldNormal};
+    const int n_dev = argc > 8 ? atoi(argv[8]) : 0;
+    Film film_single(all, Extent2u(W, H)), film_multi(all, Extent2u(W, H), std::vector<int>((size_t)(n_dev > 0 ? n_dev : 1), 0));
+    Film& film = n_dev > 0 ? film_multi : film_single;
     PathTracingIntegrator integ{(size_t)atoi(argv[5]), 2};
     const float t0 = 1.0f * (1.0f / 24.0f);
     film.render_frame_into(world, cam, integ, BlackmanHarrisFilter::new_(1.5f), Extent2u(16, 16), 1, {t0, t0 + 1.0f / 24.0f}, (size_t)atoi(argv[4]));

@@ -258,6 +258,29 @@ def test_two_workers_are_invisible(gpu_ctx, oracle):
     assert film_equal_bits(one, ref)
 
 
+def test_tuning_variants_are_invisible(oracle, monkeypatch):
+    """The optional code paths behind the tuning switches (k_shadow1 scanning the visibility bytes itself, k_shade_setup as a
+    grid-stride loop) give the same film bit for bit."""
+    import rayn_amd
+    wd, p = case("s2", 48, 32, 2, 3)
+    tabs = _tables(oracle, p)
+    ref, ctr = oracle.render(wd, p, tabs)
+    for env in ({"RAYN_HIP_SHADOW_SCAN": "1"}, {"RAYN_HIP_SETUP_STRIDE": "1"}, {"RAYN_HIP_SHADOW_SCAN": "1", "RAYN_HIP_WORKERS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = rayn_amd.Context(0)
+        try:
+            ctx.upload_world(wd)
+            out = ctx.render_host(p, tabs)
+            st = ctx.stats()
+        finally:
+            ctx.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        assert st["segments"] == ctr.segments and st["shadow_jobs"] > 0
+        assert film_equal_bits(out, ref), env
+
+
 def test_tile_partition_union(gpu_ctx, oracle):
     """tile_first/tile_step (the multi-GPU film partition): the union of the strided renders == the full frame."""
     wd, p = case("s1", 64, 48, 1, 2)

@@ -36,11 +36,13 @@ def test_world_desc_matches_python_mirror(exe, tmp_path, volumes):
 
 
 @pytest.mark.gpu
-def test_cpp_film_render_matches_oracle(exe, tmp_path, oracle):
+@pytest.mark.parametrize("n_devices", [0, 2])
+def test_cpp_film_render_matches_oracle(exe, tmp_path, oracle, n_devices):
+    """A compiled C++ host through the C ABI: single-device Film and a multi-device Film (two entries on GPU 0)."""
     from rayn_amd import params as P, setup as S
     W, H, samples, bounces = 48, 32, 2, 3
     out = str(tmp_path / "film.bin")
-    subprocess.check_call([exe, "render", str(W), str(H), str(samples), str(bounces), "1", out])
+    subprocess.check_call([exe, "render", str(W), str(H), str(samples), str(bounces), "1", out, str(n_devices)])
     raw = np.fromfile(out, np.float32)
     n = W * H
     got = {"color": raw[:3 * n].reshape(H, W, 3), "alpha": raw[3 * n:4 * n].reshape(H, W),

@@ -1,14 +1,17 @@
-"""One-off hunt for rare GPU/oracle mismatches: N seeded random scenes (the generator of tests/test_gpu_parity.py's
-test_randomised_scene_parity, larger films).  usage: fuzz_parity.py [n=60] [first_seed=100]"""
-import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+"""Hunt for rare GPU/oracle mismatches: N seeded random scenes (the generator of tests/test_gpu_parity.py's
+test_randomised_scene_parity, larger films, up to 1024 spp).  Every third scene goes through a two-entry multi-device context
+(rayn_hip_create_multi on GPU 0 twice).  usage: fuzz_parity.py [n=60] [first_seed=100]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import rayn_amd as R
 from rayn_amd import setup as S, params as P
 from oracle import oracle_py as O
 from common import film_equal_bits, film_l2
 n, first = (int(sys.argv[1]) if len(sys.argv) > 1 else 60), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
-ctx = R.Context(0)
+ctx1 = R.Context(0)
+ctx2 = R.Context([0, 0])
 bad = 0
 t_start = time.time()
 for seed in range(first, first + n):
@@ -35,7 +38,7 @@ for seed in range(first, first + n):
     if rng.integers(0, 4) == 0:
         cam.origin = R.Linear(cam.origin, rng.uniform(-3, 3, 3).astype(np.float32))
     wd = world.to_desc(cam_h)
-    samples, bounces = int(rng.choice([1, 2, 3, 4, 4, 8, 16, 33, 64, 150])), int(rng.integers(0, 9))
+    samples, bounces = int(rng.choice([1, 2, 3, 4, 4, 8, 16, 33, 64, 150, 256])), int(rng.integers(0, 9))
     if samples >= 8:  # many samples per pixel (the resolve sorts 4*samples keys): keep the film small
         w, h = max(8, w // (samples // 4 + 1)), max(6, h // 4)
     t0 = float(np.float32(rng.uniform(0.0, 3.0)))
@@ -43,6 +46,7 @@ for seed in range(first, first + n):
                        tile_size=(int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))), volume_marches=int(rng.choice([2, 2, 3, 4])))
     tabs = O.build_tables(4 * samples, bounces, p.volume_marches, p.frame, w, h)
     ref, ctr = O.render(wd, p, tabs)
+    ctx = ctx2 if seed % 3 == 0 else ctx1
     ctx.upload_world(wd)
     out = ctx.render_host(p, tabs)
     st = ctx.stats()

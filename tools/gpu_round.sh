@@ -1,12 +1,13 @@
-# Round evidence pass (one gpurun call): parity tests, then per workload (c3 = bench default, c2):
+# Round evidence pass (one gpurun call): parity tests + fuzz, then per workload (c3 = bench default, c2):
 #   rocprofv3 kernel stats (1 worker and 2 workers), PMC FETCH_SIZE / WRITE_SIZE passes, bench JSON lines.
-# usage: bash tools/gpu_round.sh <tag> [workloads...]      outputs under gpurun_out/
+# usage: bash tools/gpu_round.sh <tag> [workloads...]      outputs under gpurun_out/ and profiles/r02_*
 set -x
-TAG=${1:-v5}; shift
+TAG=${1:-v1}; shift
 WLS=${@:-c3 c2}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 900 python tools/fuzz_parity.py 150 5000 2>&1 | tail -4
 for WL in $WLS; do
   # per-kernel evidence is collected single-worker (the two-worker pipeline overlaps kernels, which inflates their durations)
   export RAYN_HIP_WORKERS=1
@@ -15,13 +16,18 @@ for WL in $WLS; do
   bash tools/gpu_pmc.sh write_$WL "WRITE_SIZE" --workload $WL > /dev/null 2>&1
   unset RAYN_HIP_WORKERS
   bash tools/gpu_profile.sh ${WL}_2workers --workload $WL > /dev/null 2>&1
-  python tools/pmc_to_json.py $WL profiles/r01_pmc_hbm_$WL.json gpurun_out/prof_${WL}_kernel_stats.csv > gpurun_out/pmc_hbm_$WL.txt
-  cp profiles/r01_pmc_hbm_$WL.json gpurun_out/
-  timeout 1200 python bench.py --workload $WL 2>&1 | tail -1 > gpurun_out/bench_${WL}_$TAG.json
-  timeout 900 python bench.py --workload $WL --fma-policy 1 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/bench_${WL}_fma1_$TAG.json
+  python tools/pmc_to_json.py $WL profiles/r02_pmc_hbm_$WL.json gpurun_out/prof_${WL}_kernel_stats.csv > gpurun_out/pmc_hbm_$WL.txt
+  cp profiles/r02_pmc_hbm_$WL.json gpurun_out/
+  cp gpurun_out/prof_${WL}_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_kernel_stats_1worker.csv
+  cp gpurun_out/prof_${WL}_2workers_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_kernel_stats_2workers.csv
+  cp gpurun_out/pmc_fetch_$WL.csv gpurun_out/r02_${WL}_${TAG}_pmc_fetch_size.csv
+  cp gpurun_out/pmc_write_$WL.csv gpurun_out/r02_${WL}_${TAG}_pmc_write_size.csv
+  timeout 1200 python bench.py --workload $WL 2>&1 | tail -1 > gpurun_out/r02_bench_${WL}_$TAG.json
+  timeout 900 python bench.py --workload $WL --fma-policy 1 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/r02_bench_${WL}_${TAG}_fma1.json
   python -c "
 import json
-for f in ('gpurun_out/bench_${WL}_$TAG.json','gpurun_out/bench_${WL}_fma1_$TAG.json'):
-    j=json.load(open(f)); print('VALUE', j['value'], j['ms_per_step']); print(j['kernel_ms']); print({k:j['roofline'][k] for k in ('kernel','achieved','frac','traffic')}); print(j['cpu_baseline'])"
+for f in ('gpurun_out/r02_bench_${WL}_$TAG.json','gpurun_out/r02_bench_${WL}_${TAG}_fma1.json'):
+    j=json.load(open(f)); print('VALUE', j['value'], j['ms_per_step']); print(j['kernel_ms']); print({k:j['roofline'][k] for k in ('kernel','achieved','frac','traffic')}); print(j['cpu_baseline'])
+    for k, v in j['roofline_hbm']['kernels'].items(): print('   ', k[:40], v['ms'], v['frac'])"
   cat gpurun_out/pmc_hbm_$WL.txt
 done

@@ -7,7 +7,10 @@ coalesced read -> x2.  WRITE_SIZE was calibrated on k_raygen (a pure streaming w
 Usage: python tools/pmc_to_json.py <tag> <out.json> [calls-csv]"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(path):
@@ -37,7 +40,8 @@ def main():
             e.update({"launches": n, "hbm_bytes_per_launch": (fb + wb) / n, "ms_total_unprofiled": ns / 1e6,
                       "hbm_GBps": (fb + wb) / ns})
         res[k.split("::")[-1]] = e
-    json.dump({"workload": tag, "corrections": {"unit": "KiB", "FETCH_SIZE": "x2 (gfx950)", "WRITE_SIZE": "x1 (calibrated on k_raygen)"},
+    from bench import kernel_source_hash
+    json.dump({"workload": tag, "source_hash": kernel_source_hash(), "corrections": {"unit": "KiB", "FETCH_SIZE": "x2 (gfx950)", "WRITE_SIZE": "x1 (calibrated on k_raygen)"},
                "kernels": res}, open(out, "w"), indent=1)
     for k, e in res.items():
         print(f"{k:24s} fetch {e['fetch_bytes']/1e9:8.2f} GB  write {e['write_bytes']/1e9:8.2f} GB  " + (f"{e['hbm_GBps']:7.0f} GB/s" if "hbm_GBps" in e else ""))
