@@ -12,7 +12,7 @@ python - "$F" > gpurun_out/pmc_$TAG.csv <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for row in csv.DictReader(open(sys.argv[1])):
-    k = row["Kernel_Name"].split("(")[0][:60]
+    k = row["Kernel_Name"].split("(")[0].split("<")[0][:60]  # drop template arguments (they contain commas)
     agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
 names = sorted({c for v in agg.values() for c in v})
 print("kernel," + ",".join(names))

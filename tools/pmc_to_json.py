@@ -15,9 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def load(path):
     out = {}
-    for row in csv.reader(open(path)):
-        if len(row) == 2 and row[0] != "kernel":
-            out[row[0].replace("void ", "").split("<")[0]] = float(row[1])
+    for line in open(path):
+        name, _, val = line.strip().rpartition(",")  # kernel names may contain commas (template arguments)
+        if name and name != "kernel":
+            out[name.replace("void ", "").split("<")[0]] = float(val)
     return out
 
 
