@@ -1,0 +1,228 @@
+/* rayn_detmath_fast.h — cheaper evaluation of the pinned elementary functions of rayn_detmath.h WITH THE SAME RESULT BITS.
+ *
+ * rayn_detmath.h defines what exp / sin_cos / tan / atan2 / powf return: the float nearest to one specific binary64 evaluation
+ * (long unfused Horner chains, truncation error < 1e-15).  The oracle evaluates exactly that.  k_shade_setup spends ~40 % of its
+ * VALU cycles in those chains (binary64 operations issue at half the f32 rate on gfx950), so the kernels COULD use this header instead:
+ *
+ *   1. evaluate a SHORTER polynomial with fused multiply-adds on the same reduced argument (same reduction operations as the
+ *      reference evaluation, so the reduced argument is bit-identical): a double d with |d - R| <= EPS * |d|, R = the reference double;
+ *   2. rounding-safety test: if (float)(d - EPS*d) == (float)(d + EPS*d), float rounding is monotonic and R lies between the two,
+ *      so (float)R is that same float: return it;
+ *   3. otherwise (about 3e-5 of the calls), and for every special case (NaN, inf, zero, huge or tiny arguments), evaluate the
+ *      reference function itself.
+ *
+ * STATUS: an evaluated alternative, NOT what the shipped kernels use (they evaluate rayn_detmath.h directly; -DRAYN_FAST_DETMATH
+ * switches them to this header).  It is correct - see the tests below - and halves the binary64 operation count, but the extra
+ * live values push k_shade_setup from 79 to ~125 VGPRs; at the kernel's 6-waves/SIMD register bound that is 228 B of scratch
+ * traffic per lane and the kernel runs 1.7x slower.  Kept because the arithmetic and its error analysis are
+ * reusable if the setup kernel is ever split.
+ *
+ * The result is bit-identical to rayn_detmath.h by construction as long as EPS really bounds |d - R|.  The analytic
+ * truncation bounds are stated per function; EPS is at least 3x larger.  tests/test_detmath.py checks on the CPU (this header compiles
+ * for the host too) 10^7..10^8 arguments per function for bit equality, measures the largest |d - R| / |d| seen (it must stay below
+ * EPS / 3) and the fallback rate; tests/test_gpu_parity.py checks the device build against the oracle through the C-ABI probe.
+ */
+#ifndef RAYN_DETMATH_FAST_H
+#define RAYN_DETMATH_FAST_H
+
+#include "rayn_detmath.h"
+
+#if defined(__HIPCC__) && defined(DMF_NOINLINE)
+#define RAYN_SLOW static __host__ __device__ __attribute__((noinline))
+#elif defined(__HIPCC__)
+#define RAYN_SLOW static __host__ __device__ inline
+#else
+#define RAYN_SLOW static __attribute__((noinline))
+#endif
+
+/* out-of-line reference evaluations (the rare path: keeps the fast callers small).  DMF_COUNT_FALLBACKS (host test builds only)
+ * counts how often they are taken. */
+#ifdef DMF_COUNT_FALLBACKS
+static unsigned long long dmf_fallbacks = 0;
+#define DMF_NOTE_FALLBACK dmf_fallbacks++
+#else
+#define DMF_NOTE_FALLBACK (void)0
+#endif
+RAYN_SLOW float dmf_slow_exp(float x) { DMF_NOTE_FALLBACK; return dm_expf(x); }
+RAYN_SLOW float dmf_slow_pow(float x, float y) { DMF_NOTE_FALLBACK; return dm_powf(x, y); }
+RAYN_SLOW void dmf_slow_sincos(float x, float* s, float* c) { DMF_NOTE_FALLBACK; dm_sincosf(x, s, c); }
+RAYN_SLOW float dmf_slow_tan(float x) { DMF_NOTE_FALLBACK; return dm_tanf(x); }
+RAYN_SLOW float dmf_slow_atan2(float y, float x) { DMF_NOTE_FALLBACK; return dm_atan2f(y, x); }
+
+/* step 2: d is within eps*|d| of the reference double; true + the float when rounding cannot differ */
+RAYN_HD bool dmf_round_safe(double d, double eps, float* out) {
+    const double e = d * eps;
+    const float lo = (float)(d - e), hi = (float)(d + e);
+    *out = lo;
+    const float a = lo < 0.0f ? -lo : lo;
+    return lo == hi && a > 1.0e-36f && a < 3.0e38f; /* normal floats only: denormal / overflow results take the reference path */
+}
+
+/* e^a, a double in (-87, 88): same reduction as dm_exp_core, Taylor through r^10 with fma.
+ * |r| <= 0.3466: truncation r^11/11! <= 2.2e-13, relative to e^r >= 0.707: 3.1e-13.  EPS_EXP = 1e-12. */
+#define DMF_EPS_EXP 1.0e-12
+RAYN_HD double dmf_exp_core(double a) {
+    const double LOG2E = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double kf = __builtin_floor(a * LOG2E + 0.5);
+    double r = (a - kf * LN2_HI) - kf * LN2_LO; /* the reference's operations: identical r */
+    double p = 1.0 / 3628800.0;
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    int k = (int)kf;
+    int k1 = k / 2, k2 = k - k1;
+    return (p * dm_pow2i(k1)) * dm_pow2i(k2);
+}
+
+RAYN_HD float dmf_expf(float xf) {
+    float out;
+    if (xf > -87.0f && xf < 88.0f && dmf_round_safe(dmf_exp_core((double)xf), DMF_EPS_EXP, &out)) return out;
+    return dmf_slow_exp(xf);
+}
+
+/* ln of a positive normal double that came from a float: same reduction as dm_log_core, series through z^8 with fma.
+ * z = s^2 <= 0.02944: truncation z^9/19 <= 8.7e-16 relative to the series (>= 1). */
+RAYN_HD double dmf_log_core(double x) {
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    uint64_t u = dm_d2u(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    double m = dm_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > 1.41421356237309514547) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double z = s * s;
+    double p = 1.0 / 17.0;
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    p = __builtin_fma(p, z, 1.0);
+    double logm = 2.0 * s * p;
+    double ef = (double)e;
+    return ef * LN2_HI + (ef * LN2_LO + logm);
+}
+
+/* x^y for finite x > 0, x != 1, finite y != 0 with |y ln x| < 87: the exponent a = y * ln x carries an absolute error
+ * <= |a| * 2e-15 <= 1.8e-13 (= relative error of e^a), plus exp's 3.1e-13.  EPS_POW = 2e-12. */
+#define DMF_EPS_POW 2.0e-12
+RAYN_HD float dmf_powf(float xf, float yf) {
+    float out;
+    if (xf > 1.0e-30f && xf < 1.0e30f && xf != 1.0f && yf != 0.0f && yf > -1.0e4f && yf < 1.0e4f) {
+        const double a = (double)yf * dmf_log_core((double)xf);
+        if (a > -87.0 && a < 88.0 && dmf_round_safe(dmf_exp_core(a), DMF_EPS_POW, &out)) return out;
+    }
+    return dmf_slow_pow(xf, yf);
+}
+
+/* sin and cos of a double, |x| < 1e4: same reduction as dm_sincos_core (identical r), sin through r^13, cos through r^12 (fma).
+ * |r| <= 0.7854: sin truncation r^15/15! <= 2.1e-14 |r|-relative 2.7e-14; cos truncation r^14/14! <= 3.9e-13, relative to
+ * cos r >= 0.707: 5.5e-13.  EPS_SINCOS = 2e-12 (applied to each output relative to itself). */
+#define DMF_EPS_SINCOS 2.0e-12
+RAYN_HD void dmf_sincos_core(double x, double* sn, double* cs) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;
+    const double PIO2_1T = 6.07710050650619224932e-11;
+    double kf = __builtin_floor(x * TWO_OVER_PI + 0.5);
+    double r = (x - kf * PIO2_1) - kf * PIO2_1T; /* the reference's operations: identical r (a fused form would differ after cancellation) */
+    double z = r * r;
+    double ps = 1.0 / 6227020800.0;
+    ps = __builtin_fma(ps, z, -1.0 / 39916800.0);
+    ps = __builtin_fma(ps, z, 1.0 / 362880.0);
+    ps = __builtin_fma(ps, z, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, z, 1.0 / 120.0);
+    ps = __builtin_fma(ps, z, -1.0 / 6.0);
+    double S = __builtin_fma(r * z, ps, r);
+    double pc = 1.0 / 479001600.0;
+    pc = __builtin_fma(pc, z, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, z, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, z, -1.0 / 720.0);
+    pc = __builtin_fma(pc, z, 1.0 / 24.0);
+    pc = __builtin_fma(pc, z, -0.5);
+    double C = __builtin_fma(z, pc, 1.0);
+    long long k = (long long)kf;
+    int q = (int)(k & 3);
+    if (q == 0) { *sn = S; *cs = C; }
+    else if (q == 1) { *sn = C; *cs = -S; }
+    else if (q == 2) { *sn = -S; *cs = -C; }
+    else { *sn = -C; *cs = S; }
+}
+
+RAYN_HD void dmf_sincosf(float xf, float* sn, float* cs) {
+    if (xf > -1.0e4f && xf < 1.0e4f) {
+        double s, c;
+        dmf_sincos_core((double)xf, &s, &c);
+        float fs, fc;
+        const bool ok_s = dmf_round_safe(s, DMF_EPS_SINCOS, &fs), ok_c = dmf_round_safe(c, DMF_EPS_SINCOS, &fc);
+        if (ok_s && ok_c) { *sn = fs; *cs = fc; return; }
+    }
+    dmf_slow_sincos(xf, sn, cs);
+}
+
+/* tan = s / c (binary64 division like the reference): relative error <= the sum of both.  EPS_TAN = 4e-12. */
+#define DMF_EPS_TAN 4.0e-12
+RAYN_HD float dmf_tanf(float xf) {
+    float out;
+    if (xf > -1.0e4f && xf < 1.0e4f) {
+        double s, c;
+        dmf_sincos_core((double)xf, &s, &c);
+        if (dmf_round_safe(s / c, DMF_EPS_TAN, &out)) return out;
+    }
+    return dmf_slow_tan(xf);
+}
+
+/* atan of t in [0, 1]: same reduction as dm_atan_core (identical u), series through z^14 with fma.
+ * z = u^2 <= 0.1716: truncation z^15/31 <= 1.1e-13 relative to the series (>= 0.94).  The later steps (base + u*p, pi/2 - a,
+ * pi - a) add terms of the same sign or subtract from a larger constant: no cancellation.  EPS_ATAN = 1e-12. */
+#define DMF_EPS_ATAN 1.0e-12
+RAYN_HD double dmf_atan_core(double t) {
+    const double PI_4 = 7.85398163397448278999e-01;
+    double base = 0.0, u = t;
+    if (t > 0.41421356237309503) { u = (t - 1.0) / (t + 1.0); base = PI_4; }
+    double z = u * u;
+    double p = 1.0 / 29.0;
+    p = __builtin_fma(p, z, -1.0 / 27.0);
+    p = __builtin_fma(p, z, 1.0 / 25.0);
+    p = __builtin_fma(p, z, -1.0 / 23.0);
+    p = __builtin_fma(p, z, 1.0 / 21.0);
+    p = __builtin_fma(p, z, -1.0 / 19.0);
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, -1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, -1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, -1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, -1.0 / 3.0);
+    p = __builtin_fma(p, z, 1.0);
+    return base + u * p;
+}
+
+RAYN_HD float dmf_atan2f(float yf, float xf) {
+    const double PI = 3.14159265358979311600e+00;
+    const double PI_2 = 1.57079632679489655800e+00;
+    const float axf = xf < 0.0f ? -xf : xf, ayf = yf < 0.0f ? -yf : yf;
+    /* ordinary operands only: both finite, neither tiny nor huge (zeros, infinities, NaN: reference path) */
+    if (axf > 1.0e-30f && axf < 1.0e30f && ayf > 1.0e-30f && ayf < 1.0e30f) {
+        const bool xneg = xf < 0.0f, yneg = yf < 0.0f;
+        const double ax = (double)axf, ay = (double)ayf;
+        double a = ay > ax ? PI_2 - dmf_atan_core(ax / ay) : dmf_atan_core(ay / ax);
+        if (xneg) a = PI - a;
+        float r;
+        if (dmf_round_safe(a, DMF_EPS_ATAN, &r)) return yneg ? -r : r;
+    }
+    return dmf_slow_atan2(yf, xf);
+}
+
+#endif /* RAYN_DETMATH_FAST_H */

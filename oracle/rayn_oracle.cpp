@@ -46,6 +46,8 @@
  *      clamped to n_lights-1 where the reference would panic on an out-of-range index.
  */
 #include "../include/rayn_detmath.h"
+#define DMF_COUNT_FALLBACKS /* host check of the kernels' fast elementary functions (oracle_detmath_fast); the oracle's path does not use them */
+#include "../include/rayn_detmath_fast.h"
 #include "../include/rayn_hip.h"
 
 #include <atomic>
@@ -1251,6 +1253,46 @@ void oracle_detmath(uint32_t op, const float* a, const float* b, float* out, uin
     }
 }
 int oracle_fma_policy() { return RAYN_FMA_POLICY; }
+/* Host check of include/rayn_detmath_fast.h (what the KERNELS evaluate; the oracle itself keeps using rayn_detmath.h): out = the fast
+ * wrapper's result for op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b); stats[0] = number of calls that fell back to the
+ * reference evaluation, stats[1] = largest |d_fast - d_ref| / |d_ref| between the two binary64 evaluations over the arguments inside
+ * the fast domain (must stay well below the EPS the rounding test assumes). */
+void oracle_detmath_fast(uint32_t op, const float* a, const float* b, float* out, uint64_t n, double* stats) {
+    dmf_fallbacks = 0;
+    double worst = 0.0;
+    auto dev = [&](double f, double r) { if (r != 0.0 && r == r && f == f) { double d = (f - r) / r; if (d < 0) d = -d; if (d > worst) worst = d; } };
+    for (uint64_t i = 0; i < n; i++) {
+        const float x = a[i], y = b[i];
+        switch (op) {
+        case 0: out[i] = dmf_expf(x); if (x > -87.0f && x < 88.0f) dev(dmf_exp_core((double)x), dm_exp_core((double)x)); break;
+        case 1: case 2: {
+            float s, c; dmf_sincosf(x, &s, &c); out[i] = op == 1 ? s : c;
+            if (x > -1.0e4f && x < 1.0e4f) { double fs, fc, rs, rc; dmf_sincos_core((double)x, &fs, &fc); dm_sincos_core((double)x, &rs, &rc); dev(fs, rs); dev(fc, rc); }
+            break;
+        }
+        case 3: out[i] = dmf_tanf(x); if (x > -1.0e4f && x < 1.0e4f) { double fs, fc, rs, rc; dmf_sincos_core((double)x, &fs, &fc); dm_sincos_core((double)x, &rs, &rc); dev(fs / fc, rs / rc); } break;
+        case 4: {
+            out[i] = dmf_atan2f(x, y);
+            const float ax = y < 0 ? -y : y, ay = x < 0 ? -x : x;
+            if (ax > 1.0e-30f && ax < 1.0e30f && ay > 1.0e-30f && ay < 1.0e30f) {
+                const double dx = ax, dy = ay;
+                dev(dy > dx ? dmf_atan_core(dx / dy) : dmf_atan_core(dy / dx), dy > dx ? dm_atan_core(dx / dy) : dm_atan_core(dy / dx));
+            }
+            break;
+        }
+        default: {
+            out[i] = dmf_powf(x, y);
+            if (x > 1.0e-30f && x < 1.0e30f && x != 1.0f && y != 0.0f && y > -1.0e4f && y < 1.0e4f) {
+                const double fa = (double)y * dmf_log_core((double)x), ra = (double)y * dm_log_core((double)x);
+                if (fa > -87.0 && fa < 88.0 && ra > -87.0 && ra < 88.0) dev(dmf_exp_core(fa), dm_exp_core(ra));
+            }
+            break;
+        }
+        }
+    }
+    stats[0] = (double)dmf_fallbacks;
+    stats[1] = worst;
+}
 
 /* Film::save_to's per-pixel post-process, src/film.rs:205-378 (N3), restated arm by arm.  kind: 0 Color, 1 Alpha,
  * 2 Background, 3 WorldNormal (ChannelKind, src/film.rs:103-120).  have_*: which channels the film holds.  Writes the 8-bit

@@ -8,11 +8,25 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/rayn_detmath.h"
+#include "../../include/rayn_detmath_fast.h"
 #include "device_scene.h"
 #include "kernels.h"
 
 #ifndef RAYN_KNS
 #define RAYN_KNS rayn_p0
+#endif
+
+#if defined(RAYN_FAST_DETMATH) && !defined(RAYN_ABLATE_DETMATH)
+/* OPT-IN (make variant VFLAGS=-DRAYN_FAST_DETMATH): evaluate the pinned elementary functions through include/rayn_detmath_fast.h -
+ * shorter fused polynomials + a rounding-safety test + the reference evaluation as the fallback; the same result bits as
+ * rayn_detmath.h (checked on 8 M arguments per function on the CPU and through the device probe), about half the binary64
+ * operations.  NOT the default: in k_shade_setup the variant needs ~125 VGPRs instead of 79 to stay out of scratch (228 B of
+ * spills at the 6-waves/SIMD bound) and runs 1.7x SLOWER (c3 1/8 share 274 vs 163 ms; c2 30.2 vs 14.7 ms) - DESIGN.md section 4. */
+#define dm_expf(x) dmf_expf(x)
+#define dm_powf(x, y) dmf_powf(x, y)
+#define dm_sincosf(x, s, c) dmf_sincosf(x, s, c)
+#define dm_atan2f(y, x) dmf_atan2f(y, x)
+#define dm_tanf(x) dmf_tanf(x)
 #endif
 
 #ifdef RAYN_ABLATE_DETMATH /* TIMING EXPERIMENT ONLY (results are wrong): hardware approximations instead of the pinned f64-evaluated functions */

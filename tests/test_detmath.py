@@ -37,3 +37,49 @@ def test_special_values(oracle):
     assert f(1, 0.0) == 0.0 and f(2, 0.0) == 1.0 and math.isnan(f(1, float("inf")))
     assert f(4, 0.0, -1.0) == np.float32(math.pi) and f(4, -0.0, -1.0) == -np.float32(math.pi) and f(4, 1.0, 0.0) == np.float32(math.pi / 2)
     assert f(5, 0.0, 2.0) == 0.0 and f(5, 1.0, 7.0) == 1.0 and f(5, 0.5, 0.0) == 1.0 and math.isnan(f(5, -1.0, 0.5))
+
+
+# ---- include/rayn_detmath_fast.h: what the KERNELS evaluate (host build of the same header, through oracle_detmath_fast) ----
+FAST_CASES = [  # op, a range, b range, EPS the header's rounding test assumes
+    (0, (-82.0, 87.0), None, 1.0e-12), (1, (-9000.0, 9000.0), None, 2.0e-12), (2, (-8.0, 8.0), None, 2.0e-12), (3, (-1.6, 1.6), None, 4.0e-12),
+    (4, None, None, 1.0e-12), (5, (0.0, 1.0), (0.05, 310.0), 2.0e-12), (5, (0.5, 40.0), (-12.0, 12.0), 2.0e-12)]
+
+
+@pytest.mark.parametrize("op,ra,rb,eps", FAST_CASES)
+def test_fast_functions_return_the_reference_bits(oracle, op, ra, rb, eps):
+    """Bit equality with the reference evaluation on 8 M arguments per case, the measured |d_fast - d_ref| / |d_ref| at most a
+    third of the EPS the rounding-safety test assumes, and a fallback rate that shows the fast path is the one that runs."""
+    import ctypes as C
+    rng = np.random.default_rng(100 + op)
+    n = 8_000_000
+    if op == 4:
+        a = (rng.standard_normal(n) * 10.0 ** rng.uniform(-4, 4, n)).astype(np.float32)
+        b = (rng.standard_normal(n) * 10.0 ** rng.uniform(-4, 4, n)).astype(np.float32)
+    else:
+        a = rng.uniform(ra[0], ra[1], n).astype(np.float32)
+        b = rng.uniform(rb[0], rb[1], n).astype(np.float32) if rb else np.zeros(n, np.float32)
+    L = oracle.lib()
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    out = np.zeros_like(a)
+    st = (C.c_double * 2)()
+    L.oracle_detmath_fast(C.c_uint32(op), fp(a), fp(b), fp(out), C.c_uint64(n), st)
+    ref = oracle.detmath(op, a, b)
+    same = (out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref))
+    assert same.all(), (int((~same).sum()), a[~same][:4], b[~same][:4])
+    assert st[1] < eps / 3.0, st[1]
+    if op != 5:
+        assert st[0] / n < 1e-3, st[0] / n  # pow: many results underflow below the normal floats and take the reference path by design
+
+
+def test_fast_functions_special_values(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 3e38, -3e38, 88.5, -87.5, 1e4, -1e4, 1e-30, 1e30, 0.5, 2.0, 300.0], np.float32)
+    a, b = [x.ravel().copy() for x in np.meshgrid(sp, sp)]
+    st = (C.c_double * 2)()
+    for op in range(6):
+        out = np.zeros_like(a)
+        L.oracle_detmath_fast(C.c_uint32(op), fp(a), fp(b), fp(out), C.c_uint64(a.size), st)
+        ref = oracle.detmath(op, a, b)
+        assert (((out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref)))).all(), op

@@ -17,12 +17,19 @@ def _rand(n, lo, hi, seed):
     return np.random.default_rng(seed).uniform(lo, hi, n).astype(np.float32)
 
 
-@pytest.mark.parametrize("op,lo,hi", [(0, -30, 5), (1, -8, 8), (2, -8, 8), (3, -1.5, 1.5), (4, -6, 6), (5, 0, 1)])
+@pytest.mark.parametrize("op,lo,hi", [(0, -30, 5), (1, -8, 8), (2, -8, 8), (3, -1.5, 1.5), (4, -6, 6), (5, 0, 1), (0, -110, 95), (1, -2e4, 2e4), (5, 0, 40)])
 def test_detmath_bit_exact(gpu_ctx, oracle, op, lo, hi):
+    """The kernels' elementary functions against the oracle's evaluation of include/rayn_detmath.h: same bits on 2 M arguments per
+    case, incl. huge / tiny results and special values.  (The same test validates a -DRAYN_FAST_DETMATH build, RAYN_HIP_LIB.)"""
     import ctypes as C
     from rayn_amd._lib import lib
-    a = _rand(200000, lo, hi, 1 + op)
-    b = _rand(200000, 0.05, 12.0, 50 + op)
+    n = 2_000_000
+    a = _rand(n, lo, hi, 1 + op)
+    b = _rand(n, 0.05, 310.0 if hi > 1 else 12.0, 50 + op)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 3e38, -3e38, 88.0, -87.0, 1e4, -1e4], np.float32)
+    a[:special.size] = special
+    b[special.size:2 * special.size] = special
+    a[special.size:2 * special.size] = _rand(special.size, lo, hi, 99)
     out = np.zeros_like(a)
     fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
     assert lib().rayn_hip_probe_detmath(gpu_ctx.h, op, fp(a), fp(b), fp(out), a.size) == 0
