@@ -39,7 +39,7 @@ pub struct RaynHitable {
     pub sdf_radius: f32,
     pub animated: u32, // closure transform_seq |t| center + center_vel * t (src/animation.rs:62-68)
     pub center_vel: RaynVec3,
-    pub _pad: u32,
+    pub scale_vel: f32, // extension: MandelBox scale = |t| scale + scale_vel * t (0 = the reference's constant)
 }
 
 /// Lambertian | Dielectric (exponent = remapped roughness, src/material.rs:167-174) | Sky | Emissive

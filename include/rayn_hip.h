@@ -83,7 +83,11 @@ typedef struct {
      * non-animated center (all the reference can express) is an exact no-op. */
     uint32_t animated;
     rayn_vec3 center_vel;
-    uint32_t _pad;
+    /* EXTENSION for RAYN_SDF_MANDELBOX (scene S3: "time-varying fold/scale params"; the reference's SDFs
+     * ignore time, src/sdf.rs:25): the scale as the closure |t| scale + scale_vel * t, evaluated - like every closure-sequenced
+     * parameter (src/animation.rs:62-68) - at the ray time of lane 0 of the packet that calls hit / occluded /
+     * get_shading_info.  0 (what a zeroed struct holds; the field used to be padding) is the reference's constant scale. */
+    float scale_vel;
 } rayn_hitable;
 
 /* ---- Material / BSDF (src/material.rs:11-38) ---------------------------------------------- */

@@ -90,7 +90,8 @@ struct BoxFold { float side_length; static BoxFold new_(float s) { return BoxFol
 struct SphereFold { float min_radius, fixed_radius; static SphereFold new_(float a, float b) { return SphereFold{a, b}; } };
 struct MandelBox {
     uint32_t iterations; BoxFold box_fold; SphereFold sphere_fold; float scale;
-    static MandelBox new_(uint32_t it, BoxFold b, SphereFold s, float scale) { return MandelBox{it, b, s, scale}; }
+    float scale_vel = 0.0f; // EXTENSION: scale(t) = scale + scale_vel * t at lane-0 time (rayn_hip.h); 0 = the reference
+    static MandelBox new_(uint32_t it, BoxFold b, SphereFold s, float scale) { MandelBox m{it, b, s, scale}; return m; }
 };
 struct SphereSDF { float radius; }; // sdfu::Sphere::new(radius)
 using SDF = std::variant<MandelBox, SphereSDF>;
@@ -163,7 +164,7 @@ struct World { // src/world.rs:7-13
                 if (t.transform_seq.animated) { o.animated = 1; o.center_vel = t.transform_seq.vel.pod(); }
                 if (const MandelBox* m = std::get_if<MandelBox>(&t.sdf)) {
                     o.sdf_kind = RAYN_SDF_MANDELBOX; o.iterations = m->iterations; o.box_side = m->box_fold.side_length;
-                    o.min_radius = m->sphere_fold.min_radius; o.fixed_radius = m->sphere_fold.fixed_radius; o.scale = m->scale;
+                    o.min_radius = m->sphere_fold.min_radius; o.fixed_radius = m->sphere_fold.fixed_radius; o.scale = m->scale; o.scale_vel = m->scale_vel;
                 } else { o.sdf_kind = RAYN_SDF_SPHERE; o.sdf_radius = std::get<SphereSDF>(t.sdf).radius; }
             }
         }

@@ -263,17 +263,24 @@ struct Counters { uint64_t paths = 0, segments = 0, packets = 0; }; /* one per w
 thread_local uint64_t tl_dist_evals = 0;
 
 /* ------------------------------------------------------------------ SDFs (sdfu::SDF) ------ */
-struct SDF { virtual ~SDF() {} virtual F4 dist(W3 p) const = 0; };
+struct SDF {
+    virtual ~SDF() {}
+    virtual F4 dist(W3 p) const = 0;
+    /* EXTENSION hook: an SDF with closure-sequenced parameters evaluates them at t0 = lane 0's time of the calling packet
+     * (src/animation.rs:62-68); the reference's SDFs ignore time, which is the default here. */
+    virtual F4 dist_at(W3 p, float /*t0*/) const { return dist(p); }
+};
 struct SphereSDF : SDF { /* sdfu::Sphere (A5) */
     F4 radius;
     F4 dist(W3 p) const override { tl_dist_evals++; return mag(p) - radius; }
 };
 struct MandelBox : SDF { /* src/sdf.rs:104-188 */
     size_t iterations; F4 scale; W3 scale_vec;
+    float scale_base = 0.0f, scale_vel = 0.0f; /* EXTENSION: scale(t) = scale_base + scale_vel * t when scale_vel != 0 */
     W3 l, neg_l, two;          /* BoxFold, src/sdf.rs:143-158 */
     F4 min_rad_sq, fixed_rad_sq; /* SphereFold, src/sdf.rs:165-179 */
     MandelBox(size_t it, float side, float min_radius, float fixed_radius, float sc) {
-        iterations = it; scale = F4(sc); scale_vec = W3::broadcast(F4(sc));
+        iterations = it; scale = F4(sc); scale_vec = W3::broadcast(F4(sc)); scale_base = sc;
         l = W3::broadcast(F4(side)); neg_l = -l; two = W3::broadcast(F4(2.0f));
         min_rad_sq = F4(min_radius * min_radius); fixed_rad_sq = F4(fixed_radius * fixed_radius);
     }
@@ -283,17 +290,20 @@ struct MandelBox : SDF { /* src/sdf.rs:104-188 */
         F4 mul = fmax4(F4(1.0f), fixed_rad_sq / fmax4(min_rad_sq, r2));
         p *= mul; dr *= mul;
     }
-    F4 dist(W3 p) const override { /* :126-140 */
+    F4 dist_with(W3 p, F4 sc) const { /* :126-140 with the scale as an argument */
         tl_dist_evals++;
         W3 offset = p; F4 one(1.0f); F4 dr = one;
+        const W3 sv = W3::broadcast(sc);
         for (size_t i = 0; i < iterations; i++) {
             box_fold(p);
             sphere_fold(p, dr);
-            p = mul_add(p, scale_vec, offset);
-            dr = mul_add(-dr, scale, one);
+            p = mul_add(p, sv, offset);
+            dr = mul_add(-dr, sc, one);
         }
         return mag(p) / abs4(dr);
     }
+    F4 dist(W3 p) const override { return dist_with(p, scale); }
+    F4 dist_at(W3 p, float t0) const override { return scale_vel != 0.0f ? dist_with(p, F4(scale_base + scale_vel * t0)) : dist_with(p, scale); }
 };
 
 /* EXTENSION, not in the reference: power-8 Mandelbulb DE, polynomial form (I. Quilez, "Mandelbulb"),
@@ -369,7 +379,8 @@ struct TracedSDF : Hitable {
         W3 dir = end - start;
         F4 max_dist = mag(dir);
         dir = dir / max_dist;
-        F4 dist = sdf->dist(start);
+        const float t0 = time.v[0];
+        F4 dist = sdf->dist_at(start, t0);
         M4 nan_mask = cmp_nan(dist, dist);
         M4 gt_mask = cmp_gt(dist, max_dist);
         M4 gt_nan_mask = gt_mask | nan_mask;
@@ -380,7 +391,7 @@ struct TracedSDF : Hitable {
             gt_nan_mask = gt | nan_mask;
             if (gt_nan_mask.move_mask() == 0xF) break;
             W3 point = mul_add(dir, W3::broadcast(t), start);
-            F4 d = sdf->dist(point);
+            F4 d = sdf->dist_at(point, t0);
             hit_mask = cmp_lt(abs4(d), fmax4(F4(0.0001f * cfg.detail_scale), F4(0.00001f * cfg.detail_scale) * t));
             M4 hit_gt_nan = hit_mask | gt_nan_mask;
             if (hit_gt_nan.move_mask() == 0xF) break;
@@ -390,12 +401,13 @@ struct TracedSDF : Hitable {
     }
     F4 hit(const WRay& ray, F4 t_max, const ThresholdFn& thr) const override { /* :59-83 */
         W3 local_origin = ray.origin - origin_at(ray.time);
-        F4 dist = sdf->dist(local_origin);
+        const float t0 = ray.time.v[0];
+        F4 dist = sdf->dist_at(local_origin, t0);
         F4 t = dist;
         M4 nan_mask = cmp_nan(t, t);
         for (uint32_t m = 0; m < cfg.max_marches; m++) {
             W3 point = mul_add(ray.dir, W3::broadcast(t), local_origin); /* Ray::point_at in the SDF's frame */
-            F4 d = sdf->dist(point);
+            F4 d = sdf->dist_at(point, t0);
             M4 hit_mask = cmp_lt(abs4(d), fmax4(F4(0.00005f * cfg.detail_scale), F4(0.05f * cfg.detail_scale) * thr(t)));
             M4 gt_mask = cmp_gt(t, t_max);
             M4 stop = hit_mask | nan_mask | gt_mask;
@@ -404,17 +416,17 @@ struct TracedSDF : Hitable {
         }
         return t;
     }
-    W3 normal_at(W3 p, F4 eps) const { /* sdfu normals_fast (A5), called at src/sdf.rs:94-96 */
+    W3 normal_at(W3 p, F4 eps, float t0) const { /* sdfu normals_fast (A5), called at src/sdf.rs:94-96 */
         F4 o(1.0f), n(-1.0f);
         W3 xyy(o, n, n), yyx(n, n, o), yxy(n, o, n), xxx(o, o, o);
-        W3 g = xyy * sdf->dist(p + xyy * eps) + yyx * sdf->dist(p + yyx * eps) +
-               yxy * sdf->dist(p + yxy * eps) + xxx * sdf->dist(p + xxx * eps);
+        W3 g = xyy * sdf->dist_at(p + xyy * eps, t0) + yyx * sdf->dist_at(p + yyx * eps, t0) +
+               yxy * sdf->dist_at(p + yxy * eps, t0) + xxx * sdf->dist_at(p + xxx * eps, t0);
         return normalized(g);
     }
     ShadingInfo get_shading_info(const WHit& hit, const ThresholdFn& hps) const override { /* :85-101 */
         W3 point = hit.point();
         F4 half_pixel_size = fmax4(F4(0.0001f), F4(cfg.detail_scale) * hps(hit.t));
-        W3 normal = normal_at(point - origin_at(hit.ray.time), half_pixel_size);
+        W3 normal = normal_at(point - origin_at(hit.ray.time), half_pixel_size, hit.ray.time.v[0]);
         return ShadingInfo{material, WShadingPoint::make(hit, point, half_pixel_size, normal)};
     }
 };
@@ -728,7 +740,11 @@ struct World {
                 hitables.push_back(std::move(s));
             } else {
                 auto t = std::make_unique<TracedSDF>();
-                if (h.sdf_kind == RAYN_SDF_MANDELBOX) t->sdf = std::make_unique<MandelBox>(h.iterations, h.box_side, h.min_radius, h.fixed_radius, h.scale);
+                if (h.sdf_kind == RAYN_SDF_MANDELBOX) {
+                    auto mb = std::make_unique<MandelBox>(h.iterations, h.box_side, h.min_radius, h.fixed_radius, h.scale);
+                    mb->scale_vel = h.scale_vel;
+                    t->sdf = std::move(mb);
+                }
                 else if (h.sdf_kind == RAYN_SDF_MANDELBULB) { auto s = std::make_unique<Mandelbulb>(); s->iterations = h.iterations; t->sdf = std::move(s); }
                 else { auto s = std::make_unique<SphereSDF>(); s->radius = F4(h.sdf_radius); t->sdf = std::move(s); }
                 t->material = h.material; t->cfg = cfg;

@@ -21,7 +21,7 @@ class Hitable(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("material", C.c_uint32), ("center", Vec3), ("radius", C.c_float),
                 ("sdf_kind", C.c_uint32), ("iterations", C.c_uint32), ("box_side", C.c_float),
                 ("min_radius", C.c_float), ("fixed_radius", C.c_float), ("scale", C.c_float),
-                ("sdf_radius", C.c_float), ("animated", C.c_uint32), ("center_vel", Vec3), ("_pad", C.c_uint32)]
+                ("sdf_radius", C.c_float), ("animated", C.c_uint32), ("center_vel", Vec3), ("scale_vel", C.c_float)]
 
 
 class Material(C.Structure):

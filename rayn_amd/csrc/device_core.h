@@ -240,15 +240,19 @@ RD float div_short(float n, float d) {
     return __builtin_fmaf(__builtin_fmaf(-d, q, n), rc, q);
 }
 
+// MandelBox scale at the packet time t0 (EXTENSION, rayn_hip.h: the closure |t| scale + scale_vel * t); constants ignore t0
+RD float sdf_scale(const DHitable& h, float t0) { return h.scale_vel != 0.0f ? h.scale + h.scale_vel * t0 : h.scale; }
+
+// 'scale' = sdf_scale(h, t0) of the calling packet (h.scale itself in the reference's time-independent case)
 template <bool COUNT>
-RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals) {
+RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
 #ifndef RAYN_COUNT_FOLDS
     if (COUNT) evals++;
 #endif
     if (h.sdf_kind == RAYN_SDF_MANDELBOX) {
         const f3 offset = p;
         float dr = 1.0f;
-        const float l = h.box_l, nl = -h.box_l, s = h.scale;
+        const float l = h.box_l, nl = -h.box_l, s = scale;
         const float mrs = h.min_rad_sq, frs = h.fixed_rad_sq;
         // if min_rad_sq > fixed_rad_sq the quotient is < 1 for every r2: never enter the block
         const float frs_eff = mrs <= frs ? frs : -1.0f;
@@ -374,12 +378,13 @@ RD f3 sphere_center(const DHitable& h, float t0) { return h.animated ? h.center 
 template <bool COUNT>
 RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, const Thr& th, float t0, uint32_t& evals) {
     o = o - sphere_center(h, t0);
-    float t = sdf_dist<COUNT>(h, o, evals);
+    const float sv = sdf_scale(h, t0);
+    float t = sdf_dist<COUNT>(h, o, evals, sv);
     const bool nan = t != t;
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
     for (uint32_t m = 0; m < sc.max_marches; m++) {
         f3 p = muladd3(d, t, o);
-        float dist = sdf_dist<COUNT>(h, p, evals);
+        float dist = sdf_dist<COUNT>(h, p, evals, sv);
         bool hit = __builtin_fabsf(dist) < fmaxs(c0, c1 * thr_at(th, t));
         bool gt = t > t_max;
         if (hit || nan || gt) break;
@@ -396,7 +401,8 @@ RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, flo
     f3 dir = end - start;
     float max_dist = mag(dir);
     dir = div_by_mag(dir, max_dist);
-    float dist0 = sdf_dist<COUNT>(h, start, evals);
+    const float sv = sdf_scale(h, t0);
+    float dist0 = sdf_dist<COUNT>(h, start, evals, sv);
     const bool nan = dist0 != dist0;
     if (sc.max_vis_marches == 0) return ((dist0 < 0.0001f) && !((dist0 > max_dist) || nan)) ? 0.0f : 1.0f;
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
@@ -404,7 +410,7 @@ RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, flo
     for (uint32_t m = 0; m < sc.max_vis_marches; m++) {
         if ((t > max_dist) || nan) return 1.0f;
         f3 p = muladd3(dir, t, start);
-        float dist = sdf_dist<COUNT>(h, p, evals);
+        float dist = sdf_dist<COUNT>(h, p, evals, sv);
         if (__builtin_fabsf(dist) < fmaxs(c0, c1 * t)) return 0.0f;
         t = t + dist;
     }
@@ -412,11 +418,11 @@ RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, flo
 }
 // sdfu normals_fast (tetrahedron), called at src/sdf.rs:94-96
 template <bool COUNT>
-RD f3 sdf_normal(const DHitable& h, f3 p, float eps, uint32_t& evals) {
-    float d1 = sdf_dist<COUNT>(h, f3{p.x + eps, p.y + -eps, p.z + -eps}, evals);
-    float d2 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + -eps, p.z + eps}, evals);
-    float d3 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + eps, p.z + -eps}, evals);
-    float d4 = sdf_dist<COUNT>(h, f3{p.x + eps, p.y + eps, p.z + eps}, evals);
+RD f3 sdf_normal(const DHitable& h, f3 p, float eps, uint32_t& evals, float sv) {
+    float d1 = sdf_dist<COUNT>(h, f3{p.x + eps, p.y + -eps, p.z + -eps}, evals, sv);
+    float d2 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + -eps, p.z + eps}, evals, sv);
+    float d3 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + eps, p.z + -eps}, evals, sv);
+    float d4 = sdf_dist<COUNT>(h, f3{p.x + eps, p.y + eps, p.z + eps}, evals, sv);
     f3 g = f3{1.0f * d1, -1.0f * d1, -1.0f * d1} + f3{-1.0f * d2, -1.0f * d2, 1.0f * d2} +
            f3{-1.0f * d3, 1.0f * d3, -1.0f * d3} + f3{1.0f * d4, 1.0f * d4, 1.0f * d4};
     return normalized(g);

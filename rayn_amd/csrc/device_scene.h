@@ -14,7 +14,7 @@ struct DHitable {
     f3 center; float radius_sq;           // Sphere: f32x4::from(radius*radius), src/sphere.rs:31,52
     float box_l, min_rad_sq, fixed_rad_sq, scale; // MandelBox (src/sdf.rs:114-122,151-158,172-179)
     float sdf_radius; uint32_t fast_div; uint32_t animated; uint32_t _pad;
-    f3 center_vel; float _pad2;
+    f3 center_vel; float scale_vel; // EXTENSION: MandelBox scale(t0) = scale + scale_vel * t0 (rayn_hip.h); 0 = constant
 };
 struct DMaterial { uint32_t kind, receives_light; float exponent, _pad; f3 a; float _p1; f3 b; float _p2; };
 struct DLight { f3 pos; float rad; f3 emission; float _pad; };

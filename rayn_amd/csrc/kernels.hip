@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
         if (marching && k == ku) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
             const f3 ol = o - sphere_center(h, t0); // the SDF's frame (extension: TracedSDF origin, zero in the reference)
             const f3 p = first ? ol : muladd3(d, t, ol);
-            const float dist = sdf_dist<COUNT>(h, p, evals);
+            const float dist = sdf_dist<COUNT>(h, p, evals, sdf_scale(h, t0));
             bool done;
             if (first) { t = dist; nan = dist != dist; first = false; m = 0; done = sc.max_marches == 0; }
             else {
@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0, evals = 0;
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
     float c_pre = 0.0f, c_post = 0.0f, t = 0.0f;
+    float c_scale = h.scale, n_scale = h.scale; // MandelBox scale at the packet time (extension; h.scale itself in the reference's case)
     // prefetched next ray
     bool n_has = false;
     uint32_t n_P = 0, n_ent = 0, n_ids = 0;
@@ -290,6 +291,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
                         n_post = closest;
                         n_ids = id | (idp << 8);
                         n_o = n_o - sphere_center(h, t0); // march in the SDF's frame (extension; zero origin in the reference)
+                        n_scale = sdf_scale(h, t0);
                         n_has = true;
                     }
                 }
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
         }
         if (!c_has && n_has) { // start the spare ray
             c_has = true; n_has = false;
-            o = n_o; d = n_d; c_pre = n_pre; c_post = n_post; c_ids = n_ids; c_P = n_P; c_ent = n_ent;
+            o = n_o; d = n_d; c_pre = n_pre; c_post = n_post; c_ids = n_ids; c_P = n_P; c_ent = n_ent; c_scale = n_scale;
             first = true;
         }
         if (__ballot(c_has) == 0) {
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
 #endif
         if (c_has) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
             const f3 p = first ? o : muladd3(d, t, o);
-            const float dist = sdf_dist<COUNT>(h, p, evals);
+            const float dist = sdf_dist<COUNT>(h, p, evals, c_scale);
             bool done;
             if (first) { t = dist; nan = dist != dist; first = false; m = 0; done = max_marches == 0; }
             else {
@@ -718,7 +720,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
         } else { // src/sdf.rs:85-101
             Thr th = make_thr(sc, depth);
             float hps = fmaxs(0.0001f, sc.detail_scale * thr_at(th, t));
-            normal = (ablate & 1u) ? f3{0.0f, 1.0f, 0.0f} : sdf_normal<COUNT>(h, point - sphere_center(h, t0), hps, evals);
+            normal = (ablate & 1u) ? f3{0.0f, 1.0f, 0.0f} : sdf_normal<COUNT>(h, point - sphere_center(h, t0), hps, evals, sdf_scale(h, t0));
             offset_by = hps;
         }
         vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
@@ -984,7 +986,7 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
         const DHitable& h = sc.h[ku];
         if (has && k == ku) {
             const f3 p = first ? start : muladd3(dir, t, start);
-            const float dist = sdf_dist<COUNT>(h, p, evals);
+            const float dist = sdf_dist<COUNT>(h, p, evals, sdf_scale(h, jt0));
             int res = -1; // -1 keep marching, 0 occluded, 1 this SDF does not occlude
             if (first) {
                 t = dist; nan = dist != dist; first = false; m = 0;
@@ -1037,6 +1039,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     uint32_t ref = 0, n_ref = 0, m = 0, evals = 0;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
     float max_dist = 0.0f, n_max = 0.0f, t = 0.0f;
+    float c_scale = h.scale, n_scale = h.scale; // MandelBox scale at the packet time (extension)
     for (;;) {
         const uint64_t lack = __ballot(!n_has);
         const uint64_t idle = __ballot(!c_has && !n_has);
@@ -1081,6 +1084,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                     const float2 j0 = nee.job_geo[3 * (size_t)n_ref], j1 = nee.job_geo[3 * (size_t)n_ref + 1], j2 = nee.job_geo[3 * (size_t)n_ref + 2];
                     const float4 ja = make_float4(j0.x, j0.y, j1.x, j1.y), jb = make_float4(j2.x, j2.y, sc.anim_spheres ? nee.t0[n_ref % (uint32_t)nee.cap] : 0.0f, 0.0f);
                     const f3 origin = sphere_center(h, jb.z); // TracedSDF origin at the packet time (extension; zero in the reference)
+                    n_scale = sdf_scale(h, jb.z);
                     n_start = f3{ja.x, ja.y, ja.z} - origin;
                     const f3 e = f3{ja.w, jb.x, jb.y} - origin;
                     n_dir = e - n_start;
@@ -1093,7 +1097,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
         }
         if (!c_has && n_has) {
             c_has = true; n_has = false;
-            start = n_start; dir = n_dir; max_dist = n_max; ref = n_ref;
+            start = n_start; dir = n_dir; max_dist = n_max; ref = n_ref; c_scale = n_scale;
             first = true;
         }
         if (__ballot(c_has) == 0) {
@@ -1105,7 +1109,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
 #endif
         if (c_has) { // TracedSDF::occluded, src/sdf.rs:25-57
             const f3 p = first ? start : muladd3(dir, t, start);
-            const float dist = sdf_dist<COUNT>(h, p, evals);
+            const float dist = sdf_dist<COUNT>(h, p, evals, c_scale);
             int res = -1; // -1 keep marching, 0 occluded, 1 visible
             if (first) {
                 t = dist; nan = dist != dist; first = false; m = 0;
@@ -1530,7 +1534,7 @@ __global__ void k_probe_dist(const DScene* __restrict__ scp, uint32_t hit_index,
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t ev = 0;
-    out[i] = sdf_dist<false>(scp->h[hit_index], f3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, ev);
+    out[i] = sdf_dist<false>(scp->h[hit_index], f3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, ev, scp->h[hit_index].scale);
 }
 __global__ void k_probe_closest(const DScene* __restrict__ scp, uint32_t depth, const float* __restrict__ org, const float* __restrict__ dir,
                                 float* __restrict__ out_t, uint32_t* __restrict__ out_obj, uint32_t n) {

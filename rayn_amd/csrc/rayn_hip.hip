@@ -166,7 +166,8 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
         d.kind = h.kind; d.material = h.material; d.sdf_kind = h.sdf_kind; d.iterations = h.iterations;
         d.center = to3(h.center);
         d.animated = h.animated ? 1u : 0u; d.center_vel = to3(h.center_vel); // Sphere::transform_seq; a TracedSDF's origin as an extension
-        if (d.animated) s.anim_spheres = 1;
+        d.scale_vel = (h.kind == RAYN_HITABLE_TRACED_SDF && h.sdf_kind == RAYN_SDF_MANDELBOX) ? h.scale_vel : 0.0f;
+        if (d.animated || d.scale_vel != 0.0f) s.anim_spheres = 1; // the kernels then carry the packet's lane-0 time
         d.radius_sq = h.radius * h.radius;
         d.box_l = h.box_side;
         d.min_rad_sq = h.min_radius * h.min_radius;

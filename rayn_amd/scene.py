@@ -75,10 +75,13 @@ class SphereFold:
 
 @dataclass
 class MandelBox:
+    """MandelBox::new(iterations, box_fold, sphere_fold, scale), src/sdf.rs:114-122.  EXTENSION: scale_vel != 0 makes the scale the
+    closure |t| scale + scale_vel * t (lane-0 time of the calling packet) - a fractal that morphs during the shutter."""
     iterations: int
     box_fold: BoxFold
     sphere_fold: SphereFold
     scale: float
+    scale_vel: float = 0.0
 
 
 @dataclass
@@ -260,6 +263,7 @@ class World:
                     o.box_side = s.box_fold.side_length
                     o.min_radius, o.fixed_radius = s.sphere_fold.min_radius, s.sphere_fold.fixed_radius
                     o.scale = s.scale
+                    o.scale_vel = s.scale_vel
                 elif isinstance(s, SphereSDF):
                     o.sdf_kind = _abi.SDF_SPHERE
                     o.sdf_radius = s.radius

@@ -378,6 +378,13 @@ def _custom_world(kind, res):
     elif kind == "moving_bulb":
         cam_h, world = S.setup_bulb(res)
         world.hitables[1].transform_seq = R.Linear(R.vec3(0.0, 0.05, 0.0), R.vec3(2.0, -1.0, 0.5))
+    elif kind == "morphing_box":  # EXTENSION: MandelBox scale as the closure |t| scale + scale_vel*t (single-SDF fast-path kernels), volume on
+        cam_h, world = S.setup(res, volumes=True, sdf="mandelbox")
+        world.hitables[1].sdf.scale_vel = 4.0
+    elif kind == "morphing_two_sdfs":  # ... in a multi-SDF scene (generic march kernels), together with a moving origin
+        world.hitables.push(R.TracedSDF(R.MandelBox(7, R.BoxFold(1.0), R.SphereFold(0.5, 1.0), -2.0, scale_vel=-3.0), 1,
+                                        R.Linear(R.vec3(0.3, 0.0, 0.0), R.vec3(0.0, 2.0, 0.0))))
+        world.hitables[1].sdf.scale_vel = 2.5
     elif kind == "lambert_sdf_sphere":
         world.hitables[1] = R.TracedSDF(R.SphereSDF(1.0), world.materials.add_material(R.Lambertian(R.Srgb(0.5, 0.5, 0.5))))
     else:
@@ -386,7 +393,7 @@ def _custom_world(kind, res):
 
 
 @pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "anim_spheres", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere",
-                                  "offset_sdf", "moving_sdf", "moving_two_sdfs", "moving_bulb"])
+                                  "offset_sdf", "moving_sdf", "moving_two_sdfs", "moving_bulb", "morphing_box", "morphing_two_sdfs"])
 def test_closed_set_parity(gpu_ctx, oracle, kind):
     from rayn_amd import params as P
     w, h, samples, bounces = 40, 32, 2, 4
@@ -571,6 +578,8 @@ def test_randomised_scene_parity(gpu_ctx, oracle, seed):
     cam.origin = (cam.origin * np.float32(rng.uniform(0.6, 1.4)) + rng.uniform(-0.5, 0.5, 3).astype(np.float32)).astype(np.float32)
     if rng.integers(0, 3) == 0:
         world.hitables[1].transform_seq = R.Linear(rng.uniform(-0.2, 0.2, 3).astype(np.float32), rng.uniform(-3, 3, 3).astype(np.float32))
+    if rng.integers(0, 3) == 0:
+        box.scale_vel = float(np.float32(rng.uniform(-3, 3)))
     wd = world.to_desc(cam_h)
     samples, bounces = int(rng.integers(1, 4)), int(rng.integers(1, 7))
     t0 = float(np.float32(rng.uniform(0.0, 2.0)))

@@ -27,6 +27,8 @@ for seed in range(first, first + n):
         box.box_fold.side_length = float(np.float32(rng.uniform(0.6, 1.5)))
         box.sphere_fold.min_radius = float(np.float32(rng.uniform(0.002, 0.7)))
         box.sphere_fold.fixed_radius = float(np.float32(rng.uniform(0.75, 2.5)))
+    if kind == "mandelbox" and rng.integers(0, 4) == 0:
+        world.hitables[1].sdf.scale_vel = float(np.float32(rng.uniform(-4, 4)))  # extension: morphing fractal
     if volumes:
         world.volume_params = R.VolumeParams(float(np.float32(rng.uniform(0.02, 0.8))), float(np.float32(rng.uniform(0.005, 0.3))))
     for L in world.lights:
