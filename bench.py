@@ -218,7 +218,9 @@ def main():
             _, ctr = O.render(wd, p0, tabs, threads=threads, tile_subset=sub)
             return time.perf_counter() - t, ctr.paths, len(sub)
         t_cal, paths_cal, k_cal = run(threads)
-        k = int(min(n_tiles, max(threads, k_cal * args.cpu_seconds / max(t_cal, 1e-3))))
+        # whole rounds of tiles per thread (>= 3, so that the expensive fractal tiles and the cheap sky tiles balance out over the pool)
+        rounds = int(min(16, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))
+        k = int(min(n_tiles, threads * rounds))
         t_cpu, paths_cpu, k_used = run(k)
         cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
                         "tile": [ct, ct], "gpu_tile": [p.tile_w, p.tile_h],

@@ -13,6 +13,8 @@
 // ballots (mbcnt) + a block scan — never atomics-append.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "device_core.h"
@@ -1506,6 +1508,178 @@ __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_resolve for 1024 < spp <= 4096 (config 5): the register-resident sort across the FOUR waves of a block, 16 keys per lane,
+// element e = tid * 16 + r.  Sub-steps inside a lane are register compare-exchanges, sub-steps inside a wave are shuffles, and
+// only the three sub-steps whose partner sits in another wave (jj >= 1024) go through LDS - the LDS version paid 78 x 32
+// dependent LDS round trips per sort at 4096 spp (12 % of a config-5 frame in r1).
+// ------------------------------------------------------------------------------------------------
+template <typename K, uint32_t KPL>
+RD void bitonic_sort_block4(K (&key)[KPL], K* exch /* [256 * KPL] */) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    constexpr uint32_t N = 256 * KPL;
+#pragma nounroll
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        const bool asc_t = ((tid * KPL) & k) == 0; // direction of this thread's elements when k >= KPL
+#pragma nounroll
+        for (uint32_t jj = k >> 1; jj >= KPL && jj > 0; jj >>= 1) {
+            const uint32_t tm = jj / KPL; // partner thread = tid ^ tm, same register
+            const bool keep_min = asc_t == ((tid & tm) == 0);
+            K o[KPL];
+            if (tm >= 64) { // partner in another wave: through LDS
+#pragma unroll
+                for (uint32_t r = 0; r < KPL; r++) exch[r * 256 + tid] = key[r];
+                __syncthreads();
+#pragma unroll
+                for (uint32_t r = 0; r < KPL; r++) o[r] = exch[r * 256 + (tid ^ tm)];
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (uint32_t r = 0; r < KPL; r++) o[r] = shfl_xor_key(key[r], tm);
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < KPL; r++) {
+                const bool take = (o[r] < key[r]) == keep_min;
+                key[r] = take ? o[r] : key[r];
+            }
+        }
+#pragma unroll
+        for (uint32_t jj = KPL / 2; jj > 0; jj >>= 1) {
+            if (jj < k) {
+#pragma unroll
+                for (uint32_t r = 0; r < KPL; r++) {
+                    if ((r & jj) == 0) {
+                        const bool asc = k < KPL ? (r & k) == 0 : asc_t;
+                        const K a = key[r], b = key[r | jj];
+                        const bool sw = (a > b) == asc;
+                        key[r] = sw ? b : a;
+                        key[r | jj] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+    (void)lane;
+}
+
+__global__ void __launch_bounds__(256) k_resolve_big(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
+                                                      float* __restrict__ out_color, float* __restrict__ out_alpha,
+                                                      float* __restrict__ out_background, float* __restrict__ out_normal) {
+    constexpr uint32_t KPL = 16, n_sort = 256 * KPL; // 4096
+    // 64 KB: the sorted samples' (r, g) and (b, flag) for the serial-sum lanes; the sort's cross-wave exchange (32 KB of u64 keys)
+    // and the sortedness check use the same memory before the staging starts
+    __shared__ __attribute__((aligned(16))) float2 rg[n_sort];
+    __shared__ __attribute__((aligned(16))) float2 bf[n_sort];
+    __shared__ uint32_t s_cnt;
+    unsigned long long* exch64 = (unsigned long long*)rg; // [4096] u64 = 32 KB = rg
+    uint32_t* exch32 = (uint32_t*)rg;
+    float* nz = (float*)bf;
+    constexpr unsigned long long NOKEY = ~0ull;
+    const DScene& sc = *scp;
+    const DTile tile = tiles[blockIdx.y];
+    const uint32_t lpix = blockIdx.x;
+    if (lpix >= tile.ew * tile.eh) return;
+    const uint32_t spp = sc.spp, tid = threadIdx.x;
+    const uint32_t P0 = tile.pool_base + lpix * spp;
+    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
+    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
+    const float n = (float)spp;
+    // ---- Color / Background in (depth, slot) order
+    unsigned long long key[KPL];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) { // sample-major: register r of thread t = sample r * 256 + t (coalesced)
+        const uint32_t i = r * 256 + tid;
+        unsigned long long k = NOKEY;
+        if (i < spp) {
+            const uint32_t info = pool.term_info[P0 + i];
+            if (info != TERM_NONE)
+                k = ((unsigned long long)(info & 0x7Fu) << 45) | ((unsigned long long)pool.term_key[P0 + i] << 13) | ((info >> 7) << 12) | i;
+        }
+        key[r] = k;
+        mine += k != NOKEY;
+        exch64[i] = k;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    bool ok = true;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * 256 + tid; ok = ok && (i + 1 >= n_sort || !(key[r] > exch64[i + 1])); }
+    if (mine) atomicAdd(&s_cnt, mine);
+    const bool sorted = __syncthreads_or(!ok) == 0; // also orders the LDS reads above before the exchange buffer is reused
+    const uint32_t cnt = s_cnt;
+    if (!sorted) bitonic_sort_block4<unsigned long long, KPL>(key, exch64); // now element tid * KPL + r
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) {
+        if (key[r] != NOKEY) {
+            const uint32_t e = sorted ? r * 256 + tid : tid * KPL + r, lo = (uint32_t)key[r];
+            const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
+            rg[e] = make_float2(c.x, c.y);
+            bf[e] = make_float2(c.z, __uint_as_float((lo >> 12) & 1u));
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const float* src = tid < 2 ? (const float*)rg + tid : (const float*)bf; // stride 2 floats
+        const uint32_t* flg = (const uint32_t*)bf + 1;
+        float c = 0.0f, b = 0.0f;
+        uint32_t e = 0;
+        for (; e + 8 <= cnt; e += 8) {
+            float v[8];
+            uint32_t f[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) { // two independent serial chains (see k_resolve_reg)
+                const bool bg = f[u] != 0;
+                c += bg ? 0.0f : v[u];
+                b += bg ? v[u] : 0.0f;
+            }
+        }
+        for (; e < cnt; e++) {
+            if (flg[2 * e]) b += src[2 * e]; else c += src[2 * e];
+        }
+        out_color[3 * fi + tid] = c / n;
+        out_background[3 * fi + tid] = b / n;
+    }
+    __syncthreads();
+    // ---- Alpha / WorldNormal: key = object:16 | sample:16
+    uint32_t k32[KPL];
+    mine = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) {
+        const uint32_t i = r * 256 + tid;
+        uint32_t k = INVALID;
+        if (i < spp) { const uint32_t ob = __float_as_uint(pool.aov[P0 + i].w); if (ob != OBJ_NONE) k = (ob << 16) | i; }
+        k32[r] = k;
+        mine += k != INVALID;
+        exch32[i] = k;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    ok = true;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * 256 + tid; ok = ok && (i + 1 >= n_sort || !(k32[r] > exch32[i + 1])); }
+    if (mine) atomicAdd(&s_cnt, mine);
+    const bool sorted0 = __syncthreads_or(!ok) == 0;
+    const uint32_t cnt0 = s_cnt;
+    if (!sorted0) bitonic_sort_block4<uint32_t, KPL>(k32, exch32);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++)
+        if (k32[r] != INVALID) {
+            const uint32_t e = sorted0 ? r * 256 + tid : tid * KPL + r;
+            const float4 a = pool.aov[P0 + (k32[r] & 0xFFFFu)];
+            rg[e] = make_float2(a.x, a.y);
+            nz[e] = a.z;
+        }
+    __syncthreads();
+    if (tid == 3) out_alpha[fi] = (float)cnt0 / n;
+    else if (tid < 2) out_normal[3 * fi + tid] = serial_sum((const float*)rg + tid, 2, cnt0) / n;
+    else if (tid == 2) out_normal[3 * fi + 2] = serial_sum(nz, 1, cnt0) / n;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Multi-device film assembly (no reference counterpart; tiles are independent, src/film.rs:439-627): a device packs the
 // pixels of the tiles it rendered into one contiguous buffer (10 floats per pixel: Color 3 | Alpha 1 | Background 3 |
 // WorldNormal 3, tile after tile, pixel-major inside a tile like the path pool), the buffer crosses xGMI with ONE peer copy,
@@ -1704,6 +1878,10 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
         else if (spp <= 256) hipLaunchKernelGGL(k_resolve_reg<4>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         else if (spp <= 512) hipLaunchKernelGGL(k_resolve_reg<8>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         else hipLaunchKernelGGL(k_resolve_reg<16>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        return;
+    }
+    if (spp <= 4096 && !getenv("RAYN_HIP_RESOLVE_LDS")) { // four waves per pixel, 16 keys per lane, register + shuffle sort
+        hipLaunchKernelGGL(k_resolve_big, grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         return;
     }
     uint32_t n_sort = 8;
