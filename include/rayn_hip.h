@@ -266,8 +266,9 @@ int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
  * A further worker is only used while every worker still gets full-size batches and the call owns >= min_paths camera
  * paths (default 2^22); min_paths = 0 forces n_workers (tests). */
 int rayn_hip_set_workers(rayn_ctx* ctx, int n_workers, uint64_t min_paths);
-/* upper limit of the path-pool capacity per worker and batch of tiles (default 2^27 paths, ~45 GB of HBM per worker for a
- * scene without volume); the effective size is also capped so that all workers together use <= 60 % of the free HBM. */
+/* upper limit of the path-pool capacity per worker and batch of tiles (default 2^28 paths, ~89 GB of HBM per worker for a
+ * scene without volume); the effective size is also capped so that all workers together use <= 60 % of the free HBM and that
+ * the 32-bit [light sample][slot] references of a batch do not overflow. */
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
 /* mul_add policy (include/rayn_detmath.h): 0 = unfused a*b+c, what rayn's default x86-64 build does (wide
  * 0.4.6 without +fma) — the DEFAULT; 1 = fused, what rayn built with -C target-feature=+fma does.

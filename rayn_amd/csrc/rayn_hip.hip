@@ -76,7 +76,7 @@ struct rayn_ctx {
     rayn_stats stats;
     unsigned long long evals[3] = {0, 0, 0}; // extend, shade_setup (normals), shadow
     bool profiling = false, counting = false;
-    size_t batch_paths = (size_t)1 << 27;   // per worker; also limited by the HBM budget (render_device)
+    size_t batch_paths = (size_t)1 << 28;   // per worker; also limited by the HBM budget and the 32-bit job refs (render_device)
     size_t two_worker_min_paths = (size_t)1 << 22;
     int n_workers = 2;
     Tuning tun;
@@ -544,8 +544,13 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         const size_t budget_paths = (size_t)(0.6 * (double)free_b) / per_path;
         const int max_w = std::min(std::min(ctx->n_workers, MAX_WORKERS), (int)std::min<size_t>(owned.size(), MAX_WORKERS));
         for (int c = std::max(max_w, 1); c >= 1; c--) {
-            const size_t cap = std::max<size_t>(4096, std::min(ctx->batch_paths, budget_paths / (size_t)c));
-            if (c == 1 || (owned_paths >= ctx->two_worker_min_paths && owned_paths >= (size_t)c * cap) ||
+            // 32-bit [sample][slot] refs: NS * (binned slots of a batch) must stay below 2^32 (5 % slack for bin padding and tile tails)
+            const size_t index_cap = (size_t)(0.95 * 4294967296.0 / (double)F.NS);
+            const size_t cap = std::max<size_t>(4096, std::min(std::min(ctx->batch_paths, index_cap), budget_paths / (size_t)c));
+            // a further worker must not cost batch size: with c workers each still gets >= 3/4 of the batch one worker would get
+            // (config 3, 651 B per path: one worker with 2^28-path batches beats two with 2^27; config 2, 331 B: both fit)
+            const size_t solo = std::max<size_t>(4096, std::min(std::min(ctx->batch_paths, index_cap), budget_paths));
+            if (c == 1 || (owned_paths >= ctx->two_worker_min_paths && owned_paths >= (size_t)c * cap && 4 * cap >= 3 * solo) ||
                 (ctx->two_worker_min_paths == 0)) { nw = c; F.batch_paths = cap; break; }
         }
     }

@@ -237,7 +237,7 @@ def test_batching_is_invisible(gpu_ctx, oracle):
     gpu_ctx.set_batch_paths(4096)
     b = gpu_ctx.render_host(p, tabs)
     assert gpu_ctx.stats()["batches"] > 1
-    gpu_ctx.set_batch_paths(1 << 27)
+    gpu_ctx.set_batch_paths(1 << 28)
     assert film_equal_bits(a, b)
 
 
@@ -254,7 +254,7 @@ def test_two_workers_are_invisible(gpu_ctx, oracle):
         st = gpu_ctx.stats()
     finally:
         gpu_ctx.set_workers(2)
-        gpu_ctx.set_batch_paths(1 << 27)
+        gpu_ctx.set_batch_paths(1 << 28)
     assert st["batches"] >= 4 and st["paths"] == ctr.paths and st["segments"] == ctr.segments
     assert film_equal_bits(out, ref)
     gpu_ctx.set_workers(1)

@@ -31,3 +31,11 @@ for f in ('gpurun_out/r02_bench_${WL}_$TAG.json','gpurun_out/r02_bench_${WL}_${T
     for k, v in j['roofline_hbm']['kernels'].items(): print('   ', k[:40], v['ms'], v['frac'])"
   cat gpurun_out/pmc_hbm_$WL.txt
 done
+# other configurations (one rank's share each) and the PCIe-inclusive rate of the host-buffer entry
+timeout 600 python tools/share_profile.py 3 8 c3 2>&1 | tail -1 | sed 's/^/c3 1\/8 share: /'
+timeout 600 python tools/share_profile.py 3 8 c2 2>&1 | tail -1 | sed 's/^/c2 1\/8 share: /'
+timeout 600 python tools/share_profile.py 3 8 c4 2>&1 | tail -1 | sed 's/^/c4 1\/8 share: /'
+timeout 600 python tools/share_profile.py 5 64 c5 2>&1 | tail -1 | sed 's/^/c5 1\/64 share: /'
+timeout 600 python tools/share_profile.py 0 1 bulb 2>&1 | tail -1 | sed 's/^/bulb: /'
+timeout 600 python tools/host_rate.py c3 2>&1 | tail -1
+timeout 600 python tools/host_rate.py c2 2>&1 | tail -1

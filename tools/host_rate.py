@@ -1,7 +1,7 @@
 """PCIe-inclusive rate: rayn_hip_render_frame with HOST buffers (tables H2D + film D2H inside the call) vs the
 device-buffer entry.  usage: host_rate.py [workload=c2]"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, rayn_amd
 from rayn_amd import setup as S
 from bench import WORKLOADS
