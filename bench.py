@@ -203,23 +203,23 @@ def main():
         threads = os.cpu_count() or 1
         # The oracle runs a tile serially on one thread (like the reference).  A 16x16 tile of this workload is about a minute
         # of one core at 1024 spp, so the CPU sample uses smaller tiles (a legal Film::render_frame_into tile_size) that hold
-        # <= 16384 paths each: same scene, resolution, spp, bounces and per-path work, bounded wall time and a balanced thread
+        # <= 4096 paths each: same scene, resolution, spp, bounces and per-path work, bounded wall time and a balanced thread
         # pool.  (Packet composition is per tile, so the CPU side's packets differ from the GPU's 16x16 tiles - stated in the
         # emitted record; parity at 16x16 is what tests/test_config_digests.py checks.)
         ct = 16
-        while ct > 1 and ct * ct * spp > 16384:
+        while ct > 1 and ct * ct * spp > 4096:
             ct //= 2
         p0 = rayn_amd.frame_params(W, H, samples, bounces, tile_size=(ct, ct))
         n_tiles = rayn_amd._lib.lib().rayn_tile_count(W, H, p0.tile_w, p0.tile_h)
-        # calibrate on one spread tile per thread, then size the sample for ~cpu_seconds
+        # calibrate on one spread tile per thread, then run whole rounds of tiles per thread for ~cpu_seconds (>= 3 rounds, so that
+        # the expensive fractal tiles and the cheap sky tiles balance out over the thread pool)
         def run(k):
             sub = np.unique(np.linspace(0, n_tiles - 1, num=min(k, n_tiles)).astype(np.uint32))
             t = time.perf_counter()
             _, ctr = O.render(wd, p0, tabs, threads=threads, tile_subset=sub)
             return time.perf_counter() - t, ctr.paths, len(sub)
         t_cal, paths_cal, k_cal = run(threads)
-        # whole rounds of tiles per thread (>= 3, so that the expensive fractal tiles and the cheap sky tiles balance out over the pool)
-        rounds = int(min(16, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))
+        rounds = int(min(32, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))
         k = int(min(n_tiles, threads * rounds))
         t_cpu, paths_cpu, k_used = run(k)
         cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
