@@ -370,31 +370,6 @@ __global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8
 }
 
 // ------------------------------------------------------------------------------------------------
-// block-wide exclusive scan of one u32 per thread (256 threads = 4 waves)
-// ------------------------------------------------------------------------------------------------
-RD uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave_tot, uint32_t* total) {
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t n = __shfl_up(inc, off);
-        if (lane >= (uint32_t)off) inc += n;
-    }
-    if (lane == 63) lds_wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 4; w++) {
-        uint32_t wt = lds_wave_tot[w];
-        if (w < wave) base += wt;
-        tot += wt;
-    }
-    __syncthreads();
-    *total = tot;
-    return base + inc - v;
-}
-
-// ------------------------------------------------------------------------------------------------
 // a14 (bins) / a26 (repack): per-tile stable offsets.  One block per tile walks the tile's groups
 // and turns per-group class counts into tile-relative output bases:
 //     out slot = class_offset[c] + (#entries of class c in earlier groups) [+ rank inside the group]
@@ -686,7 +661,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     bool is_alive = false;
     uint32_t flags = 0;
     // shadow jobs live IN PLACE: vis[s][slot] = 2 marks "SDF march pending" and the segment is parked at
-    // job_geo[2*(s*cap + slot)..]; k_shadow_list collects the pending (sample, slot) pairs.  (A compacted job list would need
+    // job_geo[3*(s*cap + slot)..]; k_shadow_list collects the pending (sample, slot) pairs.  (A compacted job list would need
     // one atomic per wave per sample on a single counter - that alone cost 0.5 s per frame.)
     auto park_job = [&](uint32_t s, f3 a, f3 b) {
         const size_t idx = s * cap + j; // 24 contiguous bytes per segment (the packet time of a moving SDF is per slot: nee.t0)
@@ -1184,48 +1159,10 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
 // ------------------------------------------------------------------------------------------------
 // a25/a27: Tile::add_sample + tile_finished (src/film.rs:54-61,82-98,167-172,660-691).
 // The reference adds a pixel's samples serially in emission order = (depth, packet slot); float
-// addition is not associative, so this kernel replays exactly that order: one wave per pixel sorts
-// the pixel's spp paths by termination key in LDS (bitonic) and three lanes (r,g,b) accumulate them
+// addition is not associative, so the resolve kernels replay exactly that order: the pixel's spp paths are sorted
+// by termination key (bitonic network in registers + wave shuffles, below) and three lanes (r,g,b) accumulate them
 // sequentially.  Alpha/WorldNormal are depth-0 samples, ordered (object, sample).
 // ------------------------------------------------------------------------------------------------
-// Keys carry their payload (the sample index) in the low bits, so the network moves one word per element.
-// Each lane owns whole compare-exchange pairs (two per trip, loads issued together): one LDS round trip per
-// step instead of one per element.
-template <typename K>
-RD void bitonic_sort_lds(K* key, uint32_t n) {
-    const uint32_t half = n >> 1;
-    for (uint32_t k = 2; k <= n; k <<= 1)
-        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-            const uint32_t lo = jj - 1;
-            for (uint32_t p0 = threadIdx.x; p0 < half; p0 += 128) {
-                const uint32_t p1 = p0 + 64;
-                const bool two = p1 < half;
-                const uint32_t i0 = ((p0 & ~lo) << 1) | (p0 & lo), l0 = i0 | jj;
-                const uint32_t i1 = two ? ((p1 & ~lo) << 1) | (p1 & lo) : i0, l1 = i1 | jj;
-                const K a0 = key[i0], b0 = key[l0], a1 = key[i1], b1 = key[l1];
-                if ((a0 > b0) == ((i0 & k) == 0)) { key[i0] = b0; key[l0] = a0; }
-                if (two && (a1 > b1) == ((i1 & k) == 0)) { key[i1] = b1; key[l1] = a1; }
-            }
-            __syncthreads();
-        }
-}
-
-// true when key[0..n) is already non-decreasing (wave-wide; n is a power of two >= 8)
-template <typename K>
-RD bool is_sorted_lds(const K* key, uint32_t n) {
-    bool ok = true;
-    for (uint32_t i = threadIdx.x; i + 1 < n; i += 64) ok = ok && !(key[i] > key[i + 1]);
-    return __ballot(!ok) == 0;
-}
-
-// number of leading entries below `none` in a sorted key array (wave-wide)
-template <typename K>
-RD uint32_t count_valid_lds(const K* key, uint32_t n, K none) {
-    uint32_t c = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 64) c += (uint32_t)__popcll(__ballot(key[i] != none));
-    return c;
-}
-
 // serial float sum of src[0], src[stride], .. (cnt terms) in index order (one lane = one channel); loads are issued eight at a time
 RD float serial_sum(const float* src, uint32_t stride, uint32_t cnt) {
     float a = 0.0f;
@@ -1241,100 +1178,8 @@ RD float serial_sum(const float* src, uint32_t stride, uint32_t cnt) {
     return a;
 }
 
-// LDS: 16 bytes per sort slot.  [0, 8n): the u64 keys of the colour pass, overwritten IN PLACE (by the lane that owns
-// the slot) with the sample's (r, g) once it is sorted; [8n, 16n): (b, background flag) pairs, later the u32 keys of the
-// AOV pass plus the normals' z.  (28 bytes per slot left one wave per CU at 4096 spp and made the sorts latency-bound.)
-__global__ void __launch_bounds__(64) k_resolve(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
-                                                 float* __restrict__ out_color, float* __restrict__ out_alpha,
-                                                 float* __restrict__ out_background, float* __restrict__ out_normal, uint32_t n_sort) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long smem64[];
-    unsigned long long* key = smem64;            // [n_sort] depth:7 | slot:32 | background:1 | sample:12
-    float2* rg = (float2*)smem64;                // the same slots after staging
-    float2* bf = (float2*)(smem64 + n_sort);     // [n_sort] (b, flag bits)
-    uint32_t* key32 = (uint32_t*)(smem64 + n_sort); // [n_sort] object:16 | sample:16 (AOV pass)
-    float* nz = (float*)(smem64 + n_sort) + n_sort; // [n_sort] normal.z (AOV pass)
-    constexpr unsigned long long NOKEY = ~0ull;
-    const DScene& sc = *scp;
-    const DTile tile = tiles[blockIdx.y];
-    const uint32_t lpix = blockIdx.x;
-    if (lpix >= tile.ew * tile.eh) return;
-    const uint32_t spp = sc.spp;
-    const uint32_t P0 = tile.pool_base + lpix * spp;
-    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
-    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
-    const float n = (float)spp;
-    // ---- Color / Background in (depth, slot) order
-    for (uint32_t i = threadIdx.x; i < n_sort; i += 64) {
-        unsigned long long k = NOKEY;
-        if (i < spp) {
-            const uint32_t info = pool.term_info[P0 + i];
-            if (info != TERM_NONE)
-                k = ((unsigned long long)(info & 0x7Fu) << 45) | ((unsigned long long)pool.term_key[P0 + i] << 13) | ((info >> 7) << 12) | i;
-        }
-        key[i] = k;
-    }
-    __syncthreads();
-    if (!is_sorted_lds(key, n_sort)) bitonic_sort_lds(key, n_sort); // sky-only pixels arrive sorted
-    const uint32_t cnt = count_valid_lds(key, n_sort, NOKEY);
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < cnt; e += 64) {
-        const uint32_t lo = (uint32_t)key[e];
-        const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
-        rg[e] = make_float2(c.x, c.y);
-        bf[e] = make_float2(c.z, __uint_as_float((lo >> 12) & 1u));
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const float* src = threadIdx.x < 2 ? (const float*)rg + threadIdx.x : (const float*)bf; // stride 2 floats
-        const uint32_t* flg = (const uint32_t*)bf + 1;
-        float c = 0.0f, b = 0.0f;
-        uint32_t e = 0;
-        for (; e + 8 <= cnt; e += 8) {
-            float v[8];
-            uint32_t f[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) {
-                // two INDEPENDENT serial chains: the accumulator a sample does not belong to adds +0.0, an exact identity here
-                // (x + 0.0 == x for every x except -0.0, and a sum that starts at +0.0 never becomes -0.0 under round-to-nearest)
-                const bool bg = f[u] != 0;
-                c += bg ? 0.0f : v[u];
-                b += bg ? v[u] : 0.0f;
-            }
-        }
-        for (; e < cnt; e++) {
-            if (flg[2 * e]) b += src[2 * e]; else c += src[2 * e];
-        }
-        out_color[3 * fi + threadIdx.x] = c / n;
-        out_background[3 * fi + threadIdx.x] = b / n;
-    }
-    __syncthreads();
-    // ---- Alpha / WorldNormal: depth-0 packets are object-major, then queue (= sample) order
-    for (uint32_t i = threadIdx.x; i < n_sort; i += 64) {
-        uint32_t k = INVALID;
-        if (i < spp) { uint32_t ob = __float_as_uint(pool.aov[P0 + i].w); if (ob != OBJ_NONE) k = (ob << 16) | i; }
-        key32[i] = k;
-    }
-    __syncthreads();
-    if (!is_sorted_lds(key32, n_sort)) bitonic_sort_lds(key32, n_sort);
-    const uint32_t cnt0 = count_valid_lds(key32, n_sort, INVALID);
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < cnt0; e += 64) {
-        const float4 a = pool.aov[P0 + (key32[e] & 0xFFFFu)];
-        rg[e] = make_float2(a.x, a.y);
-        nz[e] = a.z;
-    }
-    __syncthreads();
-    // Alpha adds 1.0 per depth-0 surface sample: every partial sum is an integer < 2^24, so the serial sum is the count
-    if (threadIdx.x == 3) out_alpha[fi] = (float)cnt0 / n;
-    else if (threadIdx.x < 2) out_normal[3 * fi + threadIdx.x] = serial_sum((const float*)rg + threadIdx.x, 2, cnt0) / n;
-    else if (threadIdx.x == 2) out_normal[3 * fi + 2] = serial_sum(nz, 1, cnt0) / n;
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_resolve for spp <= 1024: the same replay of the reference's add order, with the sort REGISTER-resident.  One wave per
-// pixel holds KPL = n_sort / 64 keys per lane.  Bitonic steps whose partner lies in the same lane are compare-exchanges
+// k_resolve_reg (spp <= 1024): one wave per pixel holds KPL = n_sort / 64 sort keys per lane, REGISTER-resident.  Bitonic steps whose partner lies in the same lane are compare-exchanges
 // between registers; the others exchange register r with lane ^ (jj / KPL) through a wave shuffle - no LDS round trip and no
 // barrier per step (the LDS version spent 55 x 8 dependent LDS round trips per sort at 1024 spp: 0.9 TB/s, 11 % of the HBM roof).
 // LDS only stages the sorted samples for the three serial-sum lanes.
@@ -1880,13 +1725,8 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
         else hipLaunchKernelGGL(k_resolve_reg<16>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         return;
     }
-    if (spp <= 4096 && !getenv("RAYN_HIP_RESOLVE_LDS")) { // four waves per pixel, 16 keys per lane, register + shuffle sort
-        hipLaunchKernelGGL(k_resolve_big, grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
-        return;
-    }
-    uint32_t n_sort = 8;
-    while (n_sort < spp) n_sort <<= 1;
-    hipLaunchKernelGGL(k_resolve, grid, dim3(64), n_sort * 16, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal, n_sort);
+    // 1024 < spp <= 4096 (the host rejects more): four waves per pixel, 16 keys per lane
+    hipLaunchKernelGGL(k_resolve_big, grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
 }
 void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {
     hipLaunchKernelGGL(k_probe_dist, grid_for(n, 256), dim3(256), 0, s, sc, hit_index, pts, out, n);
