@@ -351,12 +351,13 @@ __global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8
     // consecutive-in-stride groups per trip and issues all their loads before using any.
     const uint32_t n_entries = ctl->q_groups << 6, lane = lane_id();
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_entries; i0 += stride * QUEUE_UNROLL) { // whole waves: n_entries % 64 == 0
-        uint32_t obj[QUEUE_UNROLL];
+    constexpr uint32_t HIST_UNROLL = 8; // one byte load per group: keep more of them in flight
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_entries; i0 += stride * HIST_UNROLL) { // whole waves: n_entries % 64 == 0
+        uint32_t obj[HIST_UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) { const uint32_t i = i0 + u * stride; obj[u] = i < n_entries ? ent_obj[i] : OBJ_NONE; }
+        for (uint32_t u = 0; u < HIST_UNROLL; u++) { const uint32_t i = i0 + u * stride; obj[u] = ent_obj[i < n_entries ? i : 0u]; if (i >= n_entries) obj[u] = OBJ_NONE; }
 #pragma unroll
-        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
+        for (uint32_t u = 0; u < HIST_UNROLL; u++) {
             const uint32_t i = i0 + u * stride;
             if (i >= n_entries) break; // wave-uniform
             uint32_t mine = 0;
@@ -847,14 +848,19 @@ __global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
-// Dense list of the pending (sample, slot) pairs.  A block scans 256 * SCAN_ITEMS ids; each wave takes whole 64-id groups
+// Dense list of the pending (sample, slot) pairs.  A block scans 256 * SCAN_ITEMS ids per trip; each wave takes whole 64-id groups
 // (n_slots is a multiple of 64, so a group lies inside one sample and its sample index is wave-uniform: no per-item
-// division), counts its pending items with ballots, the block reserves its range with ONE atomic (a per-wave append on a
-// single counter saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue") and every (wave, group) writes its refs
-// densely in lane order - coalesced 256-byte stores, and consecutive list entries point at consecutive segments, which
-// keeps the shadow kernel's fetch contiguous.  List order is irrelevant to the result: it is written back by index.
+// division), counts its pending items with ballots, the block reserves its range with ONE atomic and every (wave, group) writes
+// its refs densely in lane order - coalesced stores, and consecutive list entries point at consecutive segments, which keeps
+// the shadow kernel's fetch contiguous.  List order is irrelevant to the result: it is written back by index.
+// Two things bounded this kernel at 1.5 TB/s in r1, and only fixing BOTH helped (ablations: without the stores, or without the
+// loads, it ran exactly as fast): (1) the appends go through one counter and a single address takes ~90-100 atomics/us
+// (MI355X_MICROARCH.md "dequeue") - 16 ids per thread meant 13.4 M atomics per config-3 frame = the kernel's 140 ms; 64 ids per
+// thread = 16 K ids per atomic; (2) a uniform branch around every visibility load serialised them (load - wait - ballot, once
+// per group) - all loads of a trip are now issued before the first ballot.  Together: 16.5 -> 7.7 ms per 1/8 share of config 3
+// (3.5 TB/s); either one alone: 16.5 -> 15.5-16.2 ms.
 #ifndef RAYN_SCAN_ITEMS
-#define RAYN_SCAN_ITEMS 16
+#define RAYN_SCAN_ITEMS 64
 #endif
 constexpr uint32_t SCAN_ITEMS = RAYN_SCAN_ITEMS;
 __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, DCtl* __restrict__ ctl) {
@@ -866,17 +872,25 @@ __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, DCtl*
     const size_t cap = nee.cap;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     for (uint32_t block_first = blockIdx.x * (256 * SCAN_ITEMS); block_first < n_ids; block_first += gridDim.x * (256 * SCAN_ITEMS)) {
+    // All SCAN_ITEMS visibility loads of a wave are issued before the first ballot waits for one (a uniform branch around every
+    // load used to serialise them: load - wait - ballot, 16 times per chunk, which made the kernel latency-bound at 1.5 TB/s):
+    // groups beyond the end load slot 0 and are masked afterwards.
     uint32_t refs[SCAN_ITEMS];
-    uint32_t wave_total = 0; // wave-uniform
+    uint8_t vis[SCAN_ITEMS];
 #pragma unroll
     for (uint32_t r = 0; r < SCAN_ITEMS; r++) {
         const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(block_first + (r * 4 + wave) * 64)); // first id of the group
-        refs[r] = INVALID;
-        if (g < n_ids) {
-            const uint32_t s = g / n_slots;                                   // scalar
-            const uint32_t ref = (uint32_t)(s * cap + (g - s * n_slots) + lane); // < 2^32, checked on the host
-            if (nee.vis[ref] == 2) refs[r] = ref;
-        }
+        const bool in = g < n_ids;
+        const uint32_t gc = in ? g : 0u;
+        const uint32_t s = gc / n_slots;                                       // scalar
+        refs[r] = (uint32_t)(s * cap + (gc - s * n_slots) + lane);             // < 2^32, checked on the host
+        vis[r] = nee.vis[refs[r]];
+        if (!in) refs[r] = INVALID;
+    }
+    uint32_t wave_total = 0; // wave-uniform
+#pragma unroll
+    for (uint32_t r = 0; r < SCAN_ITEMS; r++) {
+        if (vis[r] != 2) refs[r] = INVALID;
         wave_total += (uint32_t)__popcll(__ballot(refs[r] != INVALID));
     }
     if (lane == 0) s_wave[wave] = wave_total;
