@@ -7,8 +7,8 @@ HBM.  The default workload is the configuration BASELINE.json's metric is quoted
 = configs[2]: 1920x1080, 1024 spp, 8 bounces, the reference's SDF fractal + homogeneous volume; the fractal is
 a MandelBox — the reference has no Mandelbulb); it fits one GPU (2.12 G paths, rendered in
 tile batches).  --workload c2 is configs[1] (256 spp, volumes off), bulb the added Mandelbulb DE.  N>1: the SAME
-frame is partitioned by tiles (rotating round-robin) across ranks and gathered to rank 0 with one RCCL
-gather inside the timed region -> strong scaling.
+frame is partitioned by tiles (rotating round-robin) across ranks and gathered to rank 0 with one grouped RCCL
+send/recv exchange (exact per-rank pixel counts, preallocated buffers) inside the timed region -> strong scaling.
 
   python bench.py --gpus 1 --steps 2 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -234,7 +234,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "paths_per_step": paths_per_step, "tile": [p.tile_w, p.tile_h], "fma_policy": "unfused (reference default build)" if args.fma_policy == 0 else "fused (reference built with +fma)",
-                       "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one RCCL gather to rank 0 per frame" if world > 1 else "")},
+                       "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one grouped RCCL send/recv of the owned pixels to rank 0 per frame" if world > 1 else "")},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "kernel_ms": kernel_ms,
             "segments_per_step": stats["segments"] * world if world > 1 else stats["segments"],
         }
