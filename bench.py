@@ -27,10 +27,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: PMC traffic files under profiles/ are stamped with it, so a stale file is detected."""
+    """sha256 over the kernel sources, the shared math header and the build flags: PMC traffic files under profiles/ are
+    stamped with it, so a stale file is detected."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "device_core.h", "kernels.h", "device_scene.h", "rayn_hip.hip"):
+    for f in ("kernels.hip", "device_core.h", "kernels.h", "device_scene.h", "rayn_hip.hip", "Makefile", "../../include/rayn_detmath.h"):
         h.update(open(os.path.join(ROOT, "rayn_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

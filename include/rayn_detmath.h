@@ -7,7 +7,11 @@
  * platform libm lane by lane.  A path tracer is chaotic: one ulp of difference in a transcendental
  * can flip a hit/miss three bounces later.  To make "GPU == CPU oracle" a testable statement, both
  * sides evaluate these functions with THIS header: only IEEE-754 correctly-rounded +,-,*,/,sqrt,
- * floor and int<->float conversions in binary64, no FMA contraction, no libm.  The same source
+ * fusedMultiplyAdd, floor and int<->float conversions in binary64, no implicit contraction, no libm.
+ * The polynomial (Horner) steps are EXPLICIT fused multiply-adds (__builtin_fma: one rounding, defined by
+ * IEEE 754, the same result from an x86-64 FMA unit, from glibc's software fma and from gfx950's
+ * v_fma_f64) - half the binary64 instructions of the mul + add form r1 used, which matters on the GPU
+ * (k_shade_setup spends about a third of its cycles here).  The same source
  * compiled by g++ (oracle) and by hipcc for gfx950 (kernels) therefore yields bit-identical floats.
  * Internally everything is evaluated in double with truncation error < 1e-15, so the float result
  * is the correctly rounded one except in ~1e-8 of cases — i.e. it agrees with a good libm (glibc's
@@ -28,6 +32,11 @@
 #define RAYN_HD static __host__ __device__ inline
 #else
 #define RAYN_HD inline
+#endif
+#if defined(__HIPCC__) && defined(RAYN_DM_NOINLINE)
+#define RAYN_HD_CORE static __host__ __device__ __attribute__((noinline))
+#else
+#define RAYN_HD_CORE RAYN_HD
 #endif
 
 #ifndef RAYN_FMA_POLICY
@@ -54,10 +63,20 @@ RAYN_HD bool dm_isnan(float x) { return x != x; }
 RAYN_HD bool dm_isnand(double x) { return x != x; }
 
 /* 2^k as a double, k in [-1022, 1023]. */
+/* A polynomial coefficient.  On the GPU it is pinned to a scalar register pair right where it is used: left alone, the
+ * compiler keeps all ~60 coefficients of the inlined functions live in vector registers across the whole kernel
+ * (k_shade_setup then needs 161 VGPRs instead of 80).  The value is the same on both sides. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ inline double dm_k(double c) { asm volatile("" : "+s"(c)); return c; }
+#define DM_K(c) dm_k(c)
+#else
+#define DM_K(c) (c)
+#endif
+
 RAYN_HD double dm_pow2i(int k) { return dm_u2d((uint64_t)(k + 1023) << 52); }
 
 /* e^a for a double argument, returned as double; caller guarantees -745 < a < 709. */
-RAYN_HD double dm_exp_core(double a) {
+RAYN_HD_CORE double dm_exp_core(double a) {
     const double LOG2E = 1.44269504088896338700e+00;
     const double LN2_HI = 6.93147180369123816490e-01; /* 33 significant bits: k*LN2_HI exact */
     const double LN2_LO = 1.90821492927058770002e-10;
@@ -65,20 +84,20 @@ RAYN_HD double dm_exp_core(double a) {
     double r = (a - kf * LN2_HI) - kf * LN2_LO; /* |r| <= ~0.347 */
     /* Taylor through r^14/14!  (0.347^14/14! ~ 4e-18) */
     double p = 1.0 / 87178291200.0;
-    p = p * r + 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    p = __builtin_fma(p, r, DM_K(1.0 / 6227020800.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 479001600.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 39916800.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 3628800.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 362880.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 40320.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 5040.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 720.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 120.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 24.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 6.0));
+    p = __builtin_fma(p, r, DM_K(0.5));
+    p = __builtin_fma(p, r, DM_K(1.0));
+    p = __builtin_fma(p, r, DM_K(1.0));
     int k = (int)kf;
     /* split the scale so that 2^k never leaves the normal double range */
     int k1 = k / 2, k2 = k - k1;
@@ -95,7 +114,7 @@ RAYN_HD float dm_expf(float xf) {
 }
 
 /* natural log of a positive, finite double that came from a float (always a normal double). */
-RAYN_HD double dm_log_core(double x) {
+RAYN_HD_CORE double dm_log_core(double x) {
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
     uint64_t u = dm_d2u(x);
@@ -106,18 +125,18 @@ RAYN_HD double dm_log_core(double x) {
     double z = s * s;
     /* 2*atanh(s) = 2s(1 + z/3 + z^2/5 + ... + z^12/25) */
     double p = 1.0 / 25.0;
-    p = p * z + 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
+    p = __builtin_fma(p, z, DM_K(1.0 / 23.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 21.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 19.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 17.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 15.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 13.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 11.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 9.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 7.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 5.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 3.0));
+    p = __builtin_fma(p, z, DM_K(1.0));
     double logm = 2.0 * s * p;
     double ef = (double)e;
     return ef * LN2_HI + (ef * LN2_LO + logm);
@@ -148,7 +167,7 @@ RAYN_HD float dm_powf(float xf, float yf) {
 }
 
 /* sin and cos of a double; accurate for |x| up to ~1e6 (rayn's arguments are < 7). */
-RAYN_HD void dm_sincos_core(double x, double* sn, double* cs) {
+RAYN_HD_CORE void dm_sincos_core(double x, double* sn, double* cs) {
     const double TWO_OVER_PI = 6.36619772367581382433e-01;
     const double PIO2_1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
     const double PIO2_1T = 6.07710050650619224932e-11; /* pi/2 - PIO2_1 */
@@ -157,24 +176,24 @@ RAYN_HD void dm_sincos_core(double x, double* sn, double* cs) {
     double z = r * r;
     /* sin r = r + r z (s1 + z(s2 + ...)), through r^17/17! */
     double ps = 1.0 / 355687428096000.0;
-    ps = ps * z - 1.0 / 1307674368000.0;
-    ps = ps * z + 1.0 / 6227020800.0;
-    ps = ps * z - 1.0 / 39916800.0;
-    ps = ps * z + 1.0 / 362880.0;
-    ps = ps * z - 1.0 / 5040.0;
-    ps = ps * z + 1.0 / 120.0;
-    ps = ps * z - 1.0 / 6.0;
+    ps = __builtin_fma(ps, z, DM_K(-1.0 / 1307674368000.0));
+    ps = __builtin_fma(ps, z, DM_K(1.0 / 6227020800.0));
+    ps = __builtin_fma(ps, z, DM_K(-1.0 / 39916800.0));
+    ps = __builtin_fma(ps, z, DM_K(1.0 / 362880.0));
+    ps = __builtin_fma(ps, z, DM_K(-1.0 / 5040.0));
+    ps = __builtin_fma(ps, z, DM_K(1.0 / 120.0));
+    ps = __builtin_fma(ps, z, DM_K(-1.0 / 6.0));
     double S = r + r * (z * ps);
     /* cos r = 1 + z (c1 + z(c2 + ...)), through r^18/18! */
     double pc = -1.0 / 6402373705728000.0;
-    pc = pc * z + 1.0 / 20922789888000.0;
-    pc = pc * z - 1.0 / 87178291200.0;
-    pc = pc * z + 1.0 / 479001600.0;
-    pc = pc * z - 1.0 / 3628800.0;
-    pc = pc * z + 1.0 / 40320.0;
-    pc = pc * z - 1.0 / 720.0;
-    pc = pc * z + 1.0 / 24.0;
-    pc = pc * z - 0.5;
+    pc = __builtin_fma(pc, z, DM_K(1.0 / 20922789888000.0));
+    pc = __builtin_fma(pc, z, DM_K(-1.0 / 87178291200.0));
+    pc = __builtin_fma(pc, z, DM_K(1.0 / 479001600.0));
+    pc = __builtin_fma(pc, z, DM_K(-1.0 / 3628800.0));
+    pc = __builtin_fma(pc, z, DM_K(1.0 / 40320.0));
+    pc = __builtin_fma(pc, z, DM_K(-1.0 / 720.0));
+    pc = __builtin_fma(pc, z, DM_K(1.0 / 24.0));
+    pc = __builtin_fma(pc, z, DM_K(-0.5));
     double C = 1.0 + z * pc;
     long long k = (long long)kf;
     int q = (int)(k & 3);
@@ -207,36 +226,36 @@ RAYN_HD float dm_tanf(float xf) {
 }
 
 /* atan of t in [0,1]. */
-RAYN_HD double dm_atan_core(double t) {
+RAYN_HD_CORE double dm_atan_core(double t) {
     const double PI_4 = 7.85398163397448278999e-01;
     double base = 0.0, u = t;
     if (t > 0.41421356237309503) { u = (t - 1.0) / (t + 1.0); base = PI_4; }
     double z = u * u; /* z <= 0.1716 */
     /* u(1 - z/3 + z^2/5 - ... ) through z^23/47 */
     double p = -1.0 / 47.0;
-    p = p * z + 1.0 / 45.0;
-    p = p * z - 1.0 / 43.0;
-    p = p * z + 1.0 / 41.0;
-    p = p * z - 1.0 / 39.0;
-    p = p * z + 1.0 / 37.0;
-    p = p * z - 1.0 / 35.0;
-    p = p * z + 1.0 / 33.0;
-    p = p * z - 1.0 / 31.0;
-    p = p * z + 1.0 / 29.0;
-    p = p * z - 1.0 / 27.0;
-    p = p * z + 1.0 / 25.0;
-    p = p * z - 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z - 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z - 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z - 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z - 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z - 1.0 / 3.0;
-    p = p * z + 1.0;
+    p = __builtin_fma(p, z, DM_K(1.0 / 45.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 43.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 41.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 39.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 37.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 35.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 33.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 31.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 29.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 27.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 25.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 23.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 21.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 19.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 17.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 15.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 13.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 11.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 9.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 7.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 5.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 3.0));
+    p = __builtin_fma(p, z, DM_K(1.0));
     return base + u * p;
 }
 

@@ -601,11 +601,14 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
 RD bool all_zero(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 constexpr uint32_t VOL_MEMO_LIGHTS = 7; // per-light volume terms memoised in LDS (3 floats per light and thread)
 
+#ifndef RAYN_SETUP_WAVES
+#define RAYN_SETUP_WAVES 6 // waves per SIMD the register budget of k_shade_setup is set for (80 VGPRs)
+#endif
 // STRIDE: grid-stride loop over the slots (fixed grid) instead of one slot per thread with a grid sized for the batch's upper
 // bound (surplus blocks exit at once).  Both take the slot count from the control block; which one is faster is a
 // register-pressure question (the loop carries j and the count across a body that already spills) - see Tuning::setup_stride.
 template <bool COUNT, bool STRIDE>
-__global__ void __launch_bounds__(256, 6) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
+__global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                       uint32_t depth, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl, Pool pool, Nee nee,
                                                       uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt, uint32_t ablate,
                                                       unsigned long long* __restrict__ evals_out) {
