@@ -47,6 +47,19 @@ RD float fmaxs(float a, float b) { return a > b ? a : b; } // a.max(b): maxps
 RD float fmins(float a, float b) { return a < b ? a : b; } // a.min(b): minps
 RD float signum(float x) { return x != x ? x : __builtin_copysignf(1.0f, x); }
 RD float muladd(float a, float b, float c) { return rayn_muladd(a, b, c); }
+// two binary32 values in an aligned register pair: element-wise *, + and fma compile to the packed VOP3P forms
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  EXPERIMENT, off by default: see RAYN_PACKED_FOLD in sdf_dist.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef RAYN_PACKED_FOLD
+#define RAYN_PACKED_FOLD 0
+#endif
+RD v2f muladd2(v2f a, v2f b, v2f c) {
+#if RAYN_FMA_POLICY
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
 RD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; } // sdfu Lerp
 
 constexpr float PI_F = 3.14159265358979323846f;
@@ -330,6 +343,52 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
         // |c| <= |l| <= 2^60: the product 2c is exact, so ONE rounding (fma) == the reference's two (mul, add)
 #define RAYN_BOX_FMA(c, q) __builtin_fmaf(c, 2.0f, -(q))
         if (h.fast_div == 2) {
+#if RAYN_PACKED_FOLD
+            // EXPERIMENT (-DRAYN_PACKED_FOLD=1; measured r2, not shipped): the same iteration on PACKED binary32 operations
+            // (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two IEEE operations per instruction).  The state is two register
+            // pairs, (x, y) and (z, dr): the box fold's 2c - p, the squares, the sphere fold's four multiplies and the
+            // scale + offset step are 2-wide; the clamps (v_med3_f32) and the quotient have no packed form.  Every lane-level
+            // operation and its operands are the ones of RAYN_FOLD_ITER - (-dr)*s is computed as dr*(-s), the same product -
+            // and the film is bit-identical (100 GPU tests, 150 fuzz scenes).  The compiler emits exactly the intended 15
+            // VALU instructions per iteration instead of 21 - and the kernels are SLOWER: c3 1/8 share k_shadow1 885 ms vs
+            // 771 ms, k_extend1 138 vs 123 ms.  A packed binary32 instruction costs this code more than the two plain ones
+            // it replaces: the 157 TFLOP/s vector peak is not reachable by packing a dependent scalar chain.
+            v2f pxy = {p.x, p.y}, pzd = {p.z, 1.0f};
+            const v2f oxy = pxy, ozd = pzd, s2 = {s, s}, sn2 = {s, -s}, two2 = {2.0f, 2.0f};
+#define RAYN_FOLD_ITER2                                                                           \
+            {                                                                                     \
+                const v2f cxy = {__builtin_amdgcn_fmed3f(pxy.x, nl, l), __builtin_amdgcn_fmed3f(pxy.y, nl, l)}; \
+                const float cz = __builtin_amdgcn_fmed3f(pzd.x, nl, l);                           \
+                pxy = __builtin_elementwise_fma(cxy, two2, -pxy);                                 \
+                pzd.x = __builtin_fmaf(cz, 2.0f, -pzd.x);                                         \
+                float r2;                                                                         \
+                if (RAYN_FMA_POLICY) r2 = muladd(pxy.x, pxy.x, muladd(pxy.y, pxy.y, pzd.x * pzd.x)); \
+                else { const v2f q = pxy * pxy; r2 = q.x + (q.y + pzd.x * pzd.x); }               \
+                const bool fold = RAYN_FOLD_ENABLE && r2 < frs_eff;                               \
+                const unsigned long long fold_lanes = __builtin_amdgcn_ballot_w64(fold);          \
+                if (__builtin_expect(fold_lanes != 0, 0)) {                                       \
+                    RAYN_FOLD_COUNT_HOOK                                                          \
+                    if (fold) {                                                                   \
+                        const float m = div_short(frs, vmax_raw(r2, mrs));                        \
+                        const v2f m2 = {m, m};                                                    \
+                        pxy = pxy * m2; pzd = pzd * m2;                                           \
+                    }                                                                             \
+                }                                                                                 \
+                pxy = muladd2(pxy, s2, oxy);                                                      \
+                pzd = muladd2(pzd, sn2, ozd);                                                     \
+            }
+            uint32_t i = 0;
+            if (h.iterations == 12) { // the shipped iteration count (src/setup.rs:44), fully unrolled
+                RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2
+                RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2
+                i = 12;
+            }
+            for (; i + 4 <= h.iterations; i += 4) { RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 }
+            for (; i < h.iterations; i++) RAYN_FOLD_ITER2
+#undef RAYN_FOLD_ITER2
+            p = f3{pxy.x, pxy.y, pzd.x};
+            dr = pzd.y;
+#else
             // unrolled by 4 by hand (the ballot is a convergent operation, which stops the loop unroller): the taken
             // back-edge of the rolled loop costs about as much as four VALU operations per iteration
             uint32_t i = 0;
@@ -345,6 +404,7 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
                 RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
             }
             for (; i < h.iterations; i++) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
+#endif
         } else if (h.fast_div) {
             for (uint32_t i = 0; i < h.iterations; i++) RAYN_FOLD_ITER(div_nr, RAYN_BOX_FMA)
         } else {
