@@ -272,12 +272,24 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
         const float mrs = h.min_rad_sq, frs = h.fixed_rad_sq;
         // if min_rad_sq > fixed_rad_sq the quotient is < 1 for every r2: never enter the block
         const float frs_eff = mrs <= frs ? frs : -1.0f;
+        // min_radius^2 once in a vector register: vmax_raw's operands are "v", and left alone the compiler re-materialises the
+        // copy from the scalar register inside every fold block (one VALU instruction in a block of eleven)
+        float mrs_v = mrs;
+        asm("" : "+v"(mrs_v));
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
 #ifdef RAYN_ABLATE_FOLD /* timing experiment only (wrong results): never enter the sphere-fold block */
 #define RAYN_FOLD_ENABLE false
 #else
 #define RAYN_FOLD_ENABLE true
+#endif
+/* Layout hint for the wave-uniform fold test: 1 = the block is laid out inline (fall through when some lane folds, one taken
+ * branch when none does), 0 = out of line (two taken branches whenever some lane folds - which is 94 % of the iterations). */
+#ifndef RAYN_FOLD_LIKELY
+#define RAYN_FOLD_LIKELY 0
+#endif
+#ifndef RAYN_FOLD_PLAIN_IF
+#define RAYN_FOLD_PLAIN_IF 1
 #endif
 #ifndef RAYN_FOLD_BRANCHFREE
 #define RAYN_FOLD_BRANCHFREE 0
@@ -300,34 +312,45 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
             p.z = BOX(__builtin_amdgcn_fmed3f(p.z, nl, l), p.z);                              \
             /* sphere_fold: mul = max(1, R2 / max(r2min, r2)).  For r2 >= R2 (and for NaN) the quotient  \
                is <= 1, mul is exactly 1 and the multiplies are identities, so the block only matters for  \
-               lanes with r2 < R2, where the quotient is >= 1: max(1, q) == q.  The test is made         \
-               WAVE-UNIFORM (ballot -> scalar branch): a per-lane 'if' costs a         \
-               v_cmp + s_and_saveexec + taken s_cbranch_execz per iteration, measured at 15 of the loop's \
-               66 cycles (tools/ubench/fold_rate.hip); inside, only the folding lanes are enabled.  Measured \
+               lanes with r2 < R2, where the quotient is >= 1: max(1, q) == q.  Measured                  \
                (-DRAYN_COUNT_FOLDS): a lane folds in 2.4-2.9 of the 12 iterations, but SOME lane of the   \
-               wave folds in 9-11.7 of them, so this block is part of nearly every iteration. */          \
+               wave folds in 9-11.7 of them, so the block is part of nearly every iteration.  Layouts      \
+               measured on a c3 1/8 share (k_shadow1 / k_extend1 ms): plain per-lane 'if' 755 / 120.5      \
+               (shipped: v_cmp + s_and_saveexec + s_cbranch_execz, the branch taken only when NO lane      \
+               folds); wave-uniform test (ballot -> scalar branch) with the block out of line 759 / 122.2  \
+               (r1's choice: two taken branches whenever some lane folds), the same hinted likely 799 /    \
+               128 (the compiler rebuilds the ballot with two more VALU instructions); branch-free select  \
+               slower still (r1). */                                                                       \
             const float r2 = mag_sq(p);                                                       \
             const bool fold = RAYN_FOLD_ENABLE && r2 < frs_eff;                               \
             if (RAYN_FOLD_BRANCHFREE) {                                                       \
                 /* no control flow at all: every lane divides, non-folding lanes select 1.0 */ \
-                const float q = DIV(frs, vmax_raw(r2, mrs));                                  \
+                const float q = DIV(frs, vmax_raw(r2, mrs_v));                                  \
                 const float m = fold ? q : 1.0f;                                              \
                 p.x *= m; p.y *= m; p.z *= m;                                                 \
                 dr *= m;                                                                      \
+            } else if (RAYN_FOLD_PLAIN_IF) {                                                  \
+                /* per-lane 'if': v_cmp + s_and_saveexec + s_cbranch_execz, the branch taken only when NO lane folds */ \
+                if (fold) {                                                                   \
+                    RAYN_FOLD_COUNT_HOOK                                                      \
+                    const float m = DIV(frs, vmax_raw(r2, mrs_v));                              \
+                    p.x *= m; p.y *= m; p.z *= m;                                             \
+                    dr *= m;                                                                  \
+                }                                                                             \
             } else {                                                                          \
                 const unsigned long long fold_lanes = __builtin_amdgcn_ballot_w64(fold);      \
-                if (__builtin_expect(fold_lanes != 0, 0)) {                                   \
+                if (__builtin_expect(fold_lanes != 0, RAYN_FOLD_LIKELY)) {                    \
                     RAYN_FOLD_COUNT_HOOK                                                      \
                     if (RAYN_FOLD_DENSE_BELOW > 0 && __builtin_popcountll(fold_lanes) < RAYN_FOLD_DENSE_BELOW) { \
                         /* few folding lanes: run the block on ALL lanes and select (see RAYN_FOLD_DENSE_BELOW) */ \
-                        const float q = DIV(frs, vmax_raw(r2, mrs));                          \
+                        const float q = DIV(frs, vmax_raw(r2, mrs_v));                          \
                         const float m = fold ? q : 1.0f;                                      \
                         p.x *= m; p.y *= m; p.z *= m;                                         \
                         dr *= m;                                                              \
                     } else if (fold) {                                                        \
                         /* r2 is not NaN on a folding lane: ONE raw v_max_f32 (fmaxf / med3 lower to three, two of  \
                            them canonicalising no-ops) */                                     \
-                        const float m = DIV(frs, vmax_raw(r2, mrs));                          \
+                        const float m = DIV(frs, vmax_raw(r2, mrs_v));                          \
                         p.x *= m; p.y *= m; p.z *= m;                                         \
                         dr *= m;                                                              \
                     }                                                                         \
@@ -366,10 +389,10 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
                 else { const v2f q = pxy * pxy; r2 = q.x + (q.y + pzd.x * pzd.x); }               \
                 const bool fold = RAYN_FOLD_ENABLE && r2 < frs_eff;                               \
                 const unsigned long long fold_lanes = __builtin_amdgcn_ballot_w64(fold);          \
-                if (__builtin_expect(fold_lanes != 0, 0)) {                                       \
+                if (__builtin_expect(fold_lanes != 0, RAYN_FOLD_LIKELY)) {                                       \
                     RAYN_FOLD_COUNT_HOOK                                                          \
                     if (fold) {                                                                   \
-                        const float m = div_short(frs, vmax_raw(r2, mrs));                        \
+                        const float m = div_short(frs, vmax_raw(r2, mrs_v));                        \
                         const v2f m2 = {m, m};                                                    \
                         pxy = pxy * m2; pzd = pzd * m2;                                           \
                     }                                                                             \
