@@ -14,6 +14,10 @@ for WL in $WLS; do
   bash tools/gpu_profile.sh $WL --workload $WL > /dev/null 2>&1
   bash tools/gpu_pmc.sh fetch_$WL "FETCH_SIZE" --workload $WL > /dev/null 2>&1
   bash tools/gpu_pmc.sh write_$WL "WRITE_SIZE" --workload $WL > /dev/null 2>&1
+  # VALU issue counters of the same single-worker frame (two passes of four counters)
+  bash tools/gpu_pmc.sh sq1_$WL "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES" --workload $WL > /dev/null 2>&1
+  bash tools/gpu_pmc.sh sq2_$WL "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_SALU" --workload $WL > /dev/null 2>&1
+  python tools/pmc_join.py gpurun_out/pmc_sq1_$WL.csv gpurun_out/pmc_sq2_$WL.csv > gpurun_out/r02_${WL}_${TAG}_pmc_sq.csv
   unset RAYN_HIP_WORKERS
   bash tools/gpu_profile.sh ${WL}_2workers --workload $WL > /dev/null 2>&1
   python tools/pmc_to_json.py $WL profiles/r02_pmc_hbm_$WL.json gpurun_out/prof_${WL}_kernel_stats.csv > gpurun_out/pmc_hbm_$WL.txt
