@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+# dmabuf IPC is the only mode the host driver of the GPU boxes supports (RCCL fails with hipIpcGetMemHandle otherwise)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
