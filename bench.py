@@ -183,7 +183,7 @@ def main():
         for name, (ms_k, nbytes) in qk.items():
             ach = nbytes / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
             roofline_hbm["kernels"][name] = {"ms": round(ms_k, 3), "algorithmic_bytes": nbytes, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
-        # PMC traffic is measured by separate rocprofv3 --pmc passes (tools/gpu_pmc_round.sh) and committed under profiles/ with the
+        # PMC traffic is measured by separate rocprofv3 --pmc passes (tools/gpu_round.sh) and committed under profiles/ with the
         # hash of the kernel sources it was taken on; a file that does not match the sources of THIS build is not quoted.
         pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_hbm_{args.workload}.json")
         if os.path.exists(pmc_path) and world == 1 and args.fma_policy == 0:
@@ -193,6 +193,13 @@ def main():
                 if kname in pmc and "hbm_bytes_per_launch" in pmc[kname]:
                     roofline["traffic"] = pmc[kname]["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = f"profiles/r02_pmc_hbm_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, kernel sources {pj['source_hash']})"
+                if kname in pmc and "valu_inst_per_cycle_simd" in pmc[kname]:
+                    # same file, same kernel sources: SQ counters of the dominant kernel.  A wave64 binary32 VALU instruction issues at
+                    # one per 2 cycles per SIMD (what the 157.3 TFLOP/s peak is made of: 64 lanes x 2 flop / 2 cycles x 1024 SIMDs x 2.4 GHz)
+                    ipc = pmc[kname]["valu_inst_per_cycle_simd"]
+                    roofline["valu_issue"] = {"inst_per_cycle_simd": round(ipc, 4), "peak": 0.5, "frac": round(ipc / 0.5, 4),
+                                              "lanes_enabled": round(pmc[kname]["lanes_enabled"], 4),
+                                              "source": f"profiles/r02_pmc_hbm_{args.workload}.json (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
                 roofline_hbm["pmc_traffic"] = {k: {"hbm_bytes": v["hbm_bytes"], "GBps": round(v.get("hbm_GBps", 0.0), 1)} for k, v in pmc.items()}
             else:
                 roofline["traffic_note"] = f"profiles/r02_pmc_hbm_{args.workload}.json was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"

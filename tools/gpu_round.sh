@@ -20,7 +20,7 @@ for WL in $WLS; do
   python tools/pmc_join.py gpurun_out/pmc_sq1_$WL.csv gpurun_out/pmc_sq2_$WL.csv > gpurun_out/r02_${WL}_${TAG}_pmc_sq.csv
   unset RAYN_HIP_WORKERS
   bash tools/gpu_profile.sh ${WL}_2workers --workload $WL > /dev/null 2>&1
-  python tools/pmc_to_json.py $WL profiles/r02_pmc_hbm_$WL.json gpurun_out/prof_${WL}_kernel_stats.csv > gpurun_out/pmc_hbm_$WL.txt
+  python tools/pmc_to_json.py $WL profiles/r02_pmc_hbm_$WL.json gpurun_out/prof_${WL}_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_pmc_sq.csv > gpurun_out/pmc_hbm_$WL.txt
   cp profiles/r02_pmc_hbm_$WL.json gpurun_out/
   cp gpurun_out/prof_${WL}_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_kernel_stats_1worker.csv
   cp gpurun_out/prof_${WL}_2workers_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_kernel_stats_2workers.csv
