@@ -29,6 +29,29 @@
 #define CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc");
 #define CMP(x) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
 
+// integer forms that can stand in for a float compare / max on NON-NEGATIVE, non-NaN floats (same bit order)
+#define CMPU(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
+#define CMPS(x) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(x), "v"(b) : "s20", "s21");
+#define MAXU(x) asm volatile("v_max_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MINU(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MINF(x) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define ANDB(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define BFI(x) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x) : "v"(b), "v"(c));
+#define ADDU(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define SUBF(x) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(x) : "v"(b));
+#define FMAC(x) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define FMAK(x) asm volatile("v_fma_f32 %0, %0, 2.0, -%1" : "+v"(x) : "v"(b));
+KERNEL(k_cmp_u32, DECL8, REP16(CMPU))
+KERNEL(k_cmp_sdst, DECL8, REP16(CMPS))
+KERNEL(k_max_u32, DECL8, REP16(MAXU))
+KERNEL(k_min_u32, DECL8, REP16(MINU))
+KERNEL(k_min_f32, DECL8, REP16(MINF))
+KERNEL(k_and_b32, DECL8, REP16(ANDB))
+KERNEL(k_bfi_b32, DECL8, REP16(BFI))
+KERNEL(k_add_u32, DECL8, REP16(ADDU))
+KERNEL(k_sub_f32, DECL8, REP16(SUBF))
+KERNEL(k_fmac_f32, DECL8, REP16(FMAC))
+KERNEL(k_fma_neg, DECL8, REP16(FMAK))
 KERNEL(k_fma, DECL8, REP16(FMA))
 KERNEL(k_mul, DECL8, REP16(MUL))
 KERNEL(k_add, DECL8, REP16(ADD))
@@ -91,6 +114,7 @@ template <typename K> double run(K k, int blocks_per_cu, int threads) {
 int main() {
     double base = run(k_fma, 8, 256);
     RUN(k_fma) RUN(k_mul) RUN(k_add) RUN(k_med3) RUN(k_max) RUN(k_cmp) RUN(k_cndmask) RUN(k_rcp) RUN(k_sqrt) RUN(k_divscale) RUN(k_divfmas) RUN(k_divfix)
+    RUN(k_cmp_u32) RUN(k_cmp_sdst) RUN(k_max_u32) RUN(k_min_u32) RUN(k_min_f32) RUN(k_and_b32) RUN(k_bfi_b32) RUN(k_add_u32) RUN(k_sub_f32) RUN(k_fmac_f32) RUN(k_fma_neg)
     RUN(k_pkfma) RUN(k_pkmul) RUN(k_pkadd) RUN(k_fma_dep) RUN(k_dfma) RUN(k_dmul)
     return 0;
 }
