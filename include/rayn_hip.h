@@ -152,9 +152,9 @@ typedef struct {
 /* ---- arguments of Film::render_frame_into + the constants it reads ------------------------ */
 typedef struct {
     uint32_t width, height;   /* Film.res, src/film.rs:180 */
-    uint32_t samples;         /* 'samples' (spp = 4*samples), src/film.rs:391,434,439 */
+    uint32_t samples;         /* 'samples' (spp = 4*samples), src/film.rs:391,434,439; closed-set limit: <= 4096 (16384 spp) */
     uint32_t tile_w, tile_h;  /* tile_size, src/main.rs:69 */
-    uint32_t max_bounces;     /* PathTracingIntegrator.max_bounces, src/integrator.rs:34 */
+    uint32_t max_bounces;     /* PathTracingIntegrator.max_bounces, src/integrator.rs:34; closed-set limit: <= 120 */
     uint32_t volume_marches;  /* VOLUME_MARCHES_PER_SAMPLE (>= 2: samples_1d[3],[4] are indexed), src/setup.rs:25 */
     uint32_t frame;           /* seeds the sample tables, src/film.rs:434 */
     float time_start, time_end; /* time_range, src/main.rs:61-62 */

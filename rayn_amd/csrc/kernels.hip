@@ -1375,10 +1375,10 @@ __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ s
 // only the three sub-steps whose partner sits in another wave (jj >= 1024) go through LDS - the LDS version paid 78 x 32
 // dependent LDS round trips per sort at 4096 spp (12 % of a config-5 frame in r1).
 // ------------------------------------------------------------------------------------------------
-template <typename K, uint32_t KPL>
-RD void bitonic_sort_block4(K (&key)[KPL], K* exch /* [256 * KPL] */) {
+template <typename K, uint32_t KPL, uint32_t NT = 256>
+RD void bitonic_sort_block4(K (&key)[KPL], K* exch /* [NT * KPL] */) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    constexpr uint32_t N = 256 * KPL;
+    constexpr uint32_t N = NT * KPL;
 #pragma nounroll
     for (uint32_t k = 2; k <= N; k <<= 1) {
         const bool asc_t = ((tid * KPL) & k) == 0; // direction of this thread's elements when k >= KPL
@@ -1389,10 +1389,10 @@ RD void bitonic_sort_block4(K (&key)[KPL], K* exch /* [256 * KPL] */) {
             K o[KPL];
             if (tm >= 64) { // partner in another wave: through LDS
 #pragma unroll
-                for (uint32_t r = 0; r < KPL; r++) exch[r * 256 + tid] = key[r];
+                for (uint32_t r = 0; r < KPL; r++) exch[r * NT + tid] = key[r];
                 __syncthreads();
 #pragma unroll
-                for (uint32_t r = 0; r < KPL; r++) o[r] = exch[r * 256 + (tid ^ tm)];
+                for (uint32_t r = 0; r < KPL; r++) o[r] = exch[r * NT + (tid ^ tm)];
                 __syncthreads();
             } else {
 #pragma unroll
@@ -1539,6 +1539,170 @@ __global__ void __launch_bounds__(256) k_resolve_big(const DScene* __restrict__ 
     if (tid == 3) out_alpha[fi] = (float)cnt0 / n;
     else if (tid < 2) out_normal[3 * fi + tid] = serial_sum((const float*)rg + tid, 2, cnt0) / n;
     else if (tid == 2) out_normal[3 * fi + 2] = serial_sum(nz, 1, cnt0) / n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resolve for 4096 < spp <= 16384 (beyond BASELINE's configurations; the reference has no limit): the same sort across the
+// SIXTEEN waves of a 1024-thread block, 16 keys per lane.  128 KB of dynamic LDS serve in turn as the sort's cross-wave exchange
+// buffer and as the staging area of the serial sums, which run in two rounds because (r, g) and (b, flag) of 16384 samples do
+// not fit together: round one stages (r, g) for lanes 0 / 1, round two b for lane 2; the background flags of the sorted order sit
+// in a 2 KB bit table.  Sample index: 14 bits of the sort key.
+// ------------------------------------------------------------------------------------------------
+RD uint32_t flag_bit(const unsigned long long* bits, uint32_t e) { return (uint32_t)(bits[e >> 6] >> (e & 63u)) & 1u; }
+// serial sums of one channel in index order, colour and background kept apart by the flag table (two independent chains, see k_resolve_reg)
+RD void serial_sum_split(const float* src, uint32_t stride, const unsigned long long* bits, uint32_t cnt, float& c_out, float& b_out) {
+    float c = 0.0f, b = 0.0f;
+    uint32_t e = 0;
+    for (; e + 8 <= cnt; e += 8) {
+        float v[8];
+        uint32_t f[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) { v[u] = src[(e + u) * stride]; f[u] = flag_bit(bits, e + u); }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const bool bg = f[u] != 0;
+            c += bg ? 0.0f : v[u];
+            b += bg ? v[u] : 0.0f;
+        }
+    }
+    for (; e < cnt; e++) {
+        if (flag_bit(bits, e)) b += src[e * stride]; else c += src[e * stride];
+    }
+    c_out = c; b_out = b;
+}
+
+__global__ void __launch_bounds__(1024) k_resolve_huge(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
+                                                        float* __restrict__ out_color, float* __restrict__ out_alpha,
+                                                        float* __restrict__ out_background, float* __restrict__ out_normal) {
+    constexpr uint32_t NT = 1024, KPL = 16, n_sort = NT * KPL; // 16384
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[]; // n_sort * 8 bytes
+    __shared__ unsigned long long s_flags[n_sort / 64];
+    __shared__ uint32_t s_cnt;
+    unsigned long long* exch64 = (unsigned long long*)lds_dyn;
+    uint32_t* exch32 = (uint32_t*)lds_dyn;
+    float2* rg = (float2*)lds_dyn;
+    float* one = (float*)lds_dyn;
+    constexpr unsigned long long NOKEY = ~0ull;
+    const DScene& sc = *scp;
+    const DTile tile = tiles[blockIdx.y];
+    const uint32_t lpix = blockIdx.x;
+    if (lpix >= tile.ew * tile.eh) return;
+    const uint32_t spp = sc.spp, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t P0 = tile.pool_base + lpix * spp;
+    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
+    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
+    const float n = (float)spp;
+    // ---- Color / Background in (depth, slot) order
+    unsigned long long key[KPL];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) { // sample-major: register r of thread t = sample r * NT + t (coalesced)
+        const uint32_t i = r * NT + tid;
+        unsigned long long k = NOKEY;
+        if (i < spp) {
+            const uint32_t info = pool.term_info[P0 + i];
+            if (info != TERM_NONE)
+                k = ((unsigned long long)(info & 0x7Fu) << 47) | ((unsigned long long)pool.term_key[P0 + i] << 15) | ((info >> 7) << 14) | i;
+        }
+        key[r] = k;
+        mine += k != NOKEY;
+        exch64[i] = k;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    bool ok = true;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * NT + tid; ok = ok && (i + 1 >= n_sort || !(key[r] > exch64[i + 1])); }
+    if (mine) atomicAdd(&s_cnt, mine);
+    const bool sorted = __syncthreads_or(!ok) == 0; // also orders the LDS reads above before the exchange buffer is reused
+    const uint32_t cnt = s_cnt;
+    if (!sorted) bitonic_sort_block4<unsigned long long, KPL, NT>(key, exch64); // now element tid * KPL + r
+    __syncthreads();
+    // background flags of the sorted order (NOKEY elements sort last and are never read)
+    if (sorted) {
+#pragma unroll
+        for (uint32_t r = 0; r < KPL; r++) { // element r * NT + tid: the 64 lanes of a wave fill one word
+            const unsigned long long m = __ballot(key[r] != NOKEY && (((uint32_t)key[r] >> 14) & 1u));
+            if (lane == 0) s_flags[r * (NT / 64) + wave] = m;
+        }
+    } else {
+        uint32_t m16 = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < KPL; r++) m16 |= (key[r] != NOKEY && (((uint32_t)key[r] >> 14) & 1u)) ? (1u << r) : 0u;
+        ((unsigned short*)s_flags)[tid] = (unsigned short)m16; // elements tid * 16 .. + 15
+    }
+    // round one: (r, g)
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++)
+        if (key[r] != NOKEY) {
+            const uint32_t e = sorted ? r * NT + tid : tid * KPL + r;
+            const float4 c = pool.col0[P0 + ((uint32_t)key[r] & 0x3FFFu)];
+            rg[e] = make_float2(c.x, c.y);
+        }
+    __syncthreads();
+    if (tid < 2) {
+        float c, b;
+        serial_sum_split((const float*)rg + tid, 2, s_flags, cnt, c, b);
+        out_color[3 * fi + tid] = c / n;
+        out_background[3 * fi + tid] = b / n;
+    }
+    __syncthreads();
+    // round two: b
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++)
+        if (key[r] != NOKEY) {
+            const uint32_t e = sorted ? r * NT + tid : tid * KPL + r;
+            one[e] = pool.col0[P0 + ((uint32_t)key[r] & 0x3FFFu)].z;
+        }
+    __syncthreads();
+    if (tid == 0) {
+        float c, b;
+        serial_sum_split(one, 1, s_flags, cnt, c, b);
+        out_color[3 * fi + 2] = c / n;
+        out_background[3 * fi + 2] = b / n;
+    }
+    __syncthreads();
+    // ---- Alpha / WorldNormal: key = object:16 | sample:16
+    uint32_t k32[KPL];
+    mine = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) {
+        const uint32_t i = r * NT + tid;
+        uint32_t k = INVALID;
+        if (i < spp) { const uint32_t ob = __float_as_uint(pool.aov[P0 + i].w); if (ob != OBJ_NONE) k = (ob << 16) | i; }
+        k32[r] = k;
+        mine += k != INVALID;
+        exch32[i] = k;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    ok = true;
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * NT + tid; ok = ok && (i + 1 >= n_sort || !(k32[r] > exch32[i + 1])); }
+    if (mine) atomicAdd(&s_cnt, mine);
+    const bool sorted0 = __syncthreads_or(!ok) == 0;
+    const uint32_t cnt0 = s_cnt;
+    if (!sorted0) bitonic_sort_block4<uint32_t, KPL, NT>(k32, exch32);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++)
+        if (k32[r] != INVALID) {
+            const uint32_t e = sorted0 ? r * NT + tid : tid * KPL + r;
+            const float4 a = pool.aov[P0 + (k32[r] & 0xFFFFu)];
+            rg[e] = make_float2(a.x, a.y);
+        }
+    __syncthreads();
+    if (tid == 3) out_alpha[fi] = (float)cnt0 / n;
+    else if (tid < 2) out_normal[3 * fi + tid] = serial_sum((const float*)rg + tid, 2, cnt0) / n;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < KPL; r++)
+        if (k32[r] != INVALID) {
+            const uint32_t e = sorted0 ? r * NT + tid : tid * KPL + r;
+            one[e] = pool.aov[P0 + (k32[r] & 0xFFFFu)].z;
+        }
+    __syncthreads();
+    if (tid == 0) out_normal[3 * fi + 2] = serial_sum(one, 1, cnt0) / n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1742,8 +1906,14 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
         else hipLaunchKernelGGL(k_resolve_reg<16>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         return;
     }
-    // 1024 < spp <= 4096 (the host rejects more): four waves per pixel, 16 keys per lane
-    hipLaunchKernelGGL(k_resolve_big, grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+    if (spp <= 4096) { // four waves per pixel, 16 keys per lane (config 5)
+        hipLaunchKernelGGL(k_resolve_big, grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        return;
+    }
+    // 4096 < spp <= 16384 (the host rejects more): sixteen waves per pixel, 128 KB of dynamic LDS
+    constexpr int huge_lds = 16384 * 8;
+    (void)hipFuncSetAttribute((const void*)k_resolve_huge, hipFuncAttributeMaxDynamicSharedMemorySize, huge_lds); // per function AND device
+    hipLaunchKernelGGL(k_resolve_huge, grid, dim3(1024), huge_lds, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
 }
 void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {
     hipLaunchKernelGGL(k_probe_dist, grid_for(n, 256), dim3(256), 0, s, sc, hit_index, pts, out, n);

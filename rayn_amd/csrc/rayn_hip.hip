@@ -233,7 +233,7 @@ int validate(rayn_ctx* ctx, const rayn_frame_params* p) {
     if (!p->width || !p->height || !p->samples || !p->tile_w || !p->tile_h) return fail(ctx, RAYN_ERR_INVALID_ARG, "zero-sized frame, tile or sample count");
     if (p->volume_marches < 2 || p->volume_marches > 4) return fail(ctx, RAYN_ERR_INVALID_ARG, "volume_marches must be in [2,4] (samples_1d[3],[4] are indexed, src/integrator.rs:138,175)");
     if (p->max_bounces > 120) return fail(ctx, RAYN_ERR_INVALID_ARG, "max_bounces > 120 does not fit the 7-bit depth field of the termination record");
-    if (p->samples > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "spp > 4096 unsupported (the film resolve sorts a pixel's samples in the registers of one block; the sample index has 12 bits in the sort key)");
+    if (p->samples > 4096) return fail(ctx, RAYN_ERR_INVALID_ARG, "spp > 16384 unsupported (the film resolve sorts a pixel's samples in the registers of one 1024-thread block)");
     if ((uint64_t)p->tile_w * (uint64_t)p->tile_h > 1024) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile larger than 1024 pixels unsupported");
     if ((uint64_t)p->width * (uint64_t)p->height >= ((uint64_t)1 << 31)) return fail(ctx, RAYN_ERR_INVALID_ARG, "film larger than 2^31 pixels unsupported (32-bit pixel indices)");
     return RAYN_OK;

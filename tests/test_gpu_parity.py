@@ -187,7 +187,11 @@ FILM_CASES = [
     ("s1", 32, 32, 1, 3, {"frame": 7, "time_range": (0.5, 0.75)}),  # other frame seed + shutter interval
     ("s1", 32, 16, 1, 2, {"max_marches": 12, "max_vis_marches": 5}),  # march budgets exhausted: 't' is returned as a hit (src/sdf.rs:82)
     ("s1", 32, 16, 1, 2, {"sdf_detail_scale": 2.0, "world_radius": 20.0}),
-    ("s3", 6, 4, 1024, 16, {"tile_size": (2, 2)}),   # config 5's regime: 4096 spp (the supported maximum), 16 bounces, moving camera (motion blur)
+    ("s3", 6, 4, 1024, 16, {"tile_size": (2, 2)}),   # config 5's regime: 4096 spp (the four-wave resolve's maximum), 16 bounces, moving camera (motion blur)
+    ("s1", 2, 1, 1100, 3, {"tile_size": (2, 1)}),    # 4400 spp: just above 4096, not a power of two (sixteen-wave resolve, mostly padding)
+    ("s3", 4, 2, 2048, 6, {"tile_size": (2, 2)}),    # 8192 spp, moving camera
+    ("s2", 2, 2, 4096, 4, {"tile_size": (2, 2)}),    # 16384 spp (the supported maximum), volume
+    ("s1", 2, 2, 2048, 0, {"tile_size": (2, 2)}),    # 8192 spp, depth 0 only: the keys arrive sorted (the resolve's no-sort path)
     ("s1", 8, 8, 256, 12, {"tile_size": (4, 4)}),    # config 4's regime: 1024 spp, 12 bounces
     ("s2", 16, 8, 256, 8, {"tile_size": (4, 4)}),    # config 3's regime: 1024 spp (resolve sorts 1024 keys), 8 bounces, volume; 4x4 tiles keep the oracle fast
 ]
@@ -327,6 +331,11 @@ def test_errors_instead_of_panics(gpu_ctx):
     p.volume_marches = 1
     with pytest.raises(rayn_amd.film.RaynHipError):
         gpu_ctx.render_host(p, [np.zeros(8, np.float32)] * 4)
+    # closed-set limits are errors too: more than 16384 spp / more than 120 bounces
+    for samples, bounces in ((4097, 2), (1, 121)):
+        wd, p = case("s1", 2, 2, samples, bounces, tile_size=(2, 2))
+        with pytest.raises(rayn_amd.film.RaynHipError):
+            gpu_ctx.render_host(p, [np.zeros(8, np.float32)] * 4)
 
 
 # ---- the rest of the closed set (SURVEY.md section 8 f/N4): cameras, Lambertian, Box filter, odd scenes ----
