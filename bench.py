@@ -65,6 +65,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fma-policy", type=int, default=0, choices=[0, 1], help="0: unfused mul_add = rayn's default build (default); 1: fused = rayn built with +fma")
+    # test aids for the N>1 path on a box with fewer GPUs than ranks (never used by the driver's launch)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo stages the gather through host memory)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks render on cuda:0 (RCCL refuses two ranks on one device: use with --backend gloo)")
+    ap.add_argument("--check-film", action="store_true", help="N>1: rank 0 re-renders the whole frame alone after the timed region and compares it bit for bit with the gathered film")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,11 +88,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     scene, W, H, samples, bounces, desc = WORKLOADS[args.workload]
     spp = 4 * samples
@@ -101,7 +110,7 @@ def main():
     ctx.set_fma_policy(args.fma_policy)
     d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
     film = rayn_amd.film.alloc_device_film(W, H, device)
-    gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device) if world > 1 else None
+    gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo")) if world > 1 else None
 
     def step():
         ctx.render_device(p, d_tabs, film)
@@ -114,6 +123,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -123,9 +137,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = all_max(dt)
+    film_check = None
+    if world > 1 and args.check_film and rank == 0:  # outside the timed region: the whole frame on this rank alone
+        p_full = rayn_amd.frame_params(W, H, samples, bounces)
+        film_full = rayn_amd.film.alloc_device_film(W, H, device)
+        ctx.render_device(p_full, d_tabs, film_full)
+        torch.cuda.synchronize()
+        film_check = all(torch.equal(result[k].view(torch.int32), film_full[k].view(torch.int32)) for k in ("color", "alpha", "background", "normal"))
+        del film_full
     paths_per_step = W * H * spp
     value = paths_per_step * args.steps / dt / 1e6
     stats = ctx.stats()
@@ -248,6 +268,10 @@ def main():
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "kernel_ms": kernel_ms,
             "segments_per_step": stats["segments"] * world if world > 1 else stats["segments"],
         }
+        if film_check is not None:
+            out["film_check"] = film_check  # gathered film == single-rank film, bit for bit
+        if world > 1 and args.backend != "nccl":
+            out["config"]["parallelism"] += f" [TEST MODE: backend {args.backend}, gather staged through host memory" + (", all ranks on one GPU" if args.share_gpu else "") + "]"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -30,8 +30,9 @@ class FilmGather:
     all receives as one batch (a grouped ncclSend/ncclRecv on RCCL = the frame's single collective step) and scatters the
     pixels into its own film, which already holds rank 0's tiles."""
 
-    def __init__(self, width, height, tile_size, rank, world, device):
+    def __init__(self, width, height, tile_size, rank, world, device, stage_host=False):
         import torch
+        self.stage_host = stage_host  # gloo with device films (a test aid: gloo moves host tensors only)
         self.rank, self.world, self.n_pixels = rank, world, width * height
         per_rank = [owned_pixels(width, height, tile_size[0], tile_size[1], r, world) for r in range(world)]
         self.counts = [len(p) for p in per_rank]
@@ -58,11 +59,18 @@ class FilmGather:
         if self.world == 1:
             return film
         if self.rank != 0:
-            dist.send(self.pack(film), dst=0, group=group)
+            buf = self.pack(film)
+            dist.send(buf.cpu() if self.stage_host else buf, dst=0, group=group)
             return None
-        reqs = dist.batch_isend_irecv([dist.P2POp(dist.irecv, self.recv[r], r, group) for r in range(1, self.world)])
-        for q in reqs:
-            q.wait()
+        if self.stage_host:
+            for r in range(1, self.world):
+                host = self.recv[r].cpu()
+                dist.recv(host, src=r, group=group)
+                self.recv[r].copy_(host)
+        else:
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.irecv, self.recv[r], r, group) for r in range(1, self.world)])
+            for q in reqs:
+                q.wait()
         for r in range(1, self.world):
             idx, part = self.all[r], self.recv[r]
             film["color"].view(-1, 3)[idx] = part[:, 0:3]

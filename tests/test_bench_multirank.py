@@ -1,0 +1,36 @@
+"""bench.py's N>1 launch contract on ONE GPU: two ranks under torch.distributed.run share cuda:0 (RCCL refuses that, so the
+exchange runs over gloo with the gather staged through host memory - bench.py's test aids), every other line of the rank
+logic is the one the driver's 8-GPU launch executes: tile partition by tile_first / tile_step, FilmGather, barriers, max over
+ranks, one JSON line from rank 0.  --check-film makes rank 0 re-render the whole frame alone and compare bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_two_ranks_one_gpu(ranks):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_BATCH_PATHS=str(1 << 22))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0",
+           "--workload", "c1", "--backend", "gloo", "--share-gpu", "--check-film", "--cpu-seconds", "0", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["steps"] == 1 and out["scaling"] == "strong"
+    assert out["film_check"] is True
+    assert out["value"] > 0 and out["config"]["paths_per_step"] == 256 * 256 * 16
