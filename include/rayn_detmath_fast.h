@@ -1,8 +1,9 @@
 /* rayn_detmath_fast.h — cheaper evaluation of the pinned elementary functions of rayn_detmath.h WITH THE SAME RESULT BITS.
  *
  * rayn_detmath.h defines what exp / sin_cos / tan / atan2 / powf return: the float nearest to one specific binary64 evaluation
- * (long unfused Horner chains, truncation error < 1e-15).  The oracle evaluates exactly that.  k_shade_setup spends ~40 % of its
- * VALU cycles in those chains (binary64 operations issue at half the f32 rate on gfx950), so the kernels COULD use this header instead:
+ * (long Horner chains - explicit fused multiply-adds since r2, mul + add in r1 - with truncation error < 1e-15).  The oracle evaluates
+ * exactly that.  k_shade_setup spends about a fifth of its time in those functions (binary64 operations cost 1.6x an f32 one on
+ * gfx950), so the kernels COULD use this header instead:
  *
  *   1. evaluate a SHORTER polynomial with fused multiply-adds on the same reduced argument (same reduction operations as the
  *      reference evaluation, so the reduced argument is bit-identical): a double d with |d - R| <= EPS * |d|, R = the reference double;
