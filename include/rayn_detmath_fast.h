@@ -13,10 +13,13 @@
  *      reference function itself.
  *
  * STATUS: an evaluated alternative, NOT what the shipped kernels use (they evaluate rayn_detmath.h directly; -DRAYN_FAST_DETMATH
- * switches them to this header).  It is correct - see the tests below - and halves the binary64 operation count, but the extra
- * live values push k_shade_setup from 79 to ~125 VGPRs; at the kernel's 6-waves/SIMD register bound that is 228 B of scratch
- * traffic per lane and the kernel runs 1.7x slower.  Kept because the arithmetic and its error analysis are
- * reusable if the setup kernel is ever split.
+ * switches them to this header).  It is correct - see the tests below - and halves the binary64 polynomial work.  First measurement
+ * (r2, coefficients as plain literals): k_shade_setup went from 79 to ~125 VGPRs, 228 B of scratch per lane at the kernel's
+ * 6-waves/SIMD register bound, 1.7x slower.  The cause was the compiler hoisting every coefficient of the fused steps into a vector
+ * register pair (see DM_K in rayn_detmath.h); with the coefficients pinned to scalar registers the variant needs 79 VGPRs / 16 B of
+ * scratch and k_shade_setup is 1.4 % FASTER than the shipped kernel (153.6 vs 155.7 ms per 1/8 share of config 3, bit-identical in
+ * the fuzz run) - a gain of 0.2 % of the frame, which says the polynomial chains are not where the pinned functions spend their
+ * time (range reduction, binary64 divisions and conversions are).  Not shipped in r2: measured after the round's evidence run.
  *
  * The result is bit-identical to rayn_detmath.h by construction as long as EPS really bounds |d - R|.  The analytic
  * truncation bounds are stated per function; EPS is at least 3x larger.  tests/test_detmath.py checks on the CPU (this header compiles
@@ -69,16 +72,16 @@ RAYN_HD double dmf_exp_core(double a) {
     double kf = __builtin_floor(a * LOG2E + 0.5);
     double r = (a - kf * LN2_HI) - kf * LN2_LO; /* the reference's operations: identical r */
     double p = 1.0 / 3628800.0;
-    p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, DM_K(1.0 / 362880.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 40320.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 5040.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 720.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 120.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 24.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 6.0));
+    p = __builtin_fma(p, r, DM_K(0.5));
+    p = __builtin_fma(p, r, DM_K(1.0));
+    p = __builtin_fma(p, r, DM_K(1.0));
     int k = (int)kf;
     int k1 = k / 2, k2 = k - k1;
     return (p * dm_pow2i(k1)) * dm_pow2i(k2);
@@ -102,14 +105,14 @@ RAYN_HD double dmf_log_core(double x) {
     double s = (m - 1.0) / (m + 1.0);
     double z = s * s;
     double p = 1.0 / 17.0;
-    p = __builtin_fma(p, z, 1.0 / 15.0);
-    p = __builtin_fma(p, z, 1.0 / 13.0);
-    p = __builtin_fma(p, z, 1.0 / 11.0);
-    p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, 1.0 / 7.0);
-    p = __builtin_fma(p, z, 1.0 / 5.0);
-    p = __builtin_fma(p, z, 1.0 / 3.0);
-    p = __builtin_fma(p, z, 1.0);
+    p = __builtin_fma(p, z, DM_K(1.0 / 15.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 13.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 11.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 9.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 7.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 5.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 3.0));
+    p = __builtin_fma(p, z, DM_K(1.0));
     double logm = 2.0 * s * p;
     double ef = (double)e;
     return ef * LN2_HI + (ef * LN2_LO + logm);
@@ -139,19 +142,19 @@ RAYN_HD void dmf_sincos_core(double x, double* sn, double* cs) {
     double r = (x - kf * PIO2_1) - kf * PIO2_1T; /* the reference's operations: identical r (a fused form would differ after cancellation) */
     double z = r * r;
     double ps = 1.0 / 6227020800.0;
-    ps = __builtin_fma(ps, z, -1.0 / 39916800.0);
-    ps = __builtin_fma(ps, z, 1.0 / 362880.0);
-    ps = __builtin_fma(ps, z, -1.0 / 5040.0);
-    ps = __builtin_fma(ps, z, 1.0 / 120.0);
-    ps = __builtin_fma(ps, z, -1.0 / 6.0);
+    ps = __builtin_fma(ps, z, DM_K(-1.0 / 39916800.0));
+    ps = __builtin_fma(ps, z, DM_K(1.0 / 362880.0));
+    ps = __builtin_fma(ps, z, DM_K(-1.0 / 5040.0));
+    ps = __builtin_fma(ps, z, DM_K(1.0 / 120.0));
+    ps = __builtin_fma(ps, z, DM_K(-1.0 / 6.0));
     double S = __builtin_fma(r * z, ps, r);
     double pc = 1.0 / 479001600.0;
-    pc = __builtin_fma(pc, z, -1.0 / 3628800.0);
-    pc = __builtin_fma(pc, z, 1.0 / 40320.0);
-    pc = __builtin_fma(pc, z, -1.0 / 720.0);
-    pc = __builtin_fma(pc, z, 1.0 / 24.0);
-    pc = __builtin_fma(pc, z, -0.5);
-    double C = __builtin_fma(z, pc, 1.0);
+    pc = __builtin_fma(pc, z, DM_K(-1.0 / 3628800.0));
+    pc = __builtin_fma(pc, z, DM_K(1.0 / 40320.0));
+    pc = __builtin_fma(pc, z, DM_K(-1.0 / 720.0));
+    pc = __builtin_fma(pc, z, DM_K(1.0 / 24.0));
+    pc = __builtin_fma(pc, z, DM_K(-0.5));
+    double C = __builtin_fma(z, pc, DM_K(1.0));
     long long k = (long long)kf;
     int q = (int)(k & 3);
     if (q == 0) { *sn = S; *cs = C; }
@@ -193,20 +196,20 @@ RAYN_HD double dmf_atan_core(double t) {
     if (t > 0.41421356237309503) { u = (t - 1.0) / (t + 1.0); base = PI_4; }
     double z = u * u;
     double p = 1.0 / 29.0;
-    p = __builtin_fma(p, z, -1.0 / 27.0);
-    p = __builtin_fma(p, z, 1.0 / 25.0);
-    p = __builtin_fma(p, z, -1.0 / 23.0);
-    p = __builtin_fma(p, z, 1.0 / 21.0);
-    p = __builtin_fma(p, z, -1.0 / 19.0);
-    p = __builtin_fma(p, z, 1.0 / 17.0);
-    p = __builtin_fma(p, z, -1.0 / 15.0);
-    p = __builtin_fma(p, z, 1.0 / 13.0);
-    p = __builtin_fma(p, z, -1.0 / 11.0);
-    p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, -1.0 / 7.0);
-    p = __builtin_fma(p, z, 1.0 / 5.0);
-    p = __builtin_fma(p, z, -1.0 / 3.0);
-    p = __builtin_fma(p, z, 1.0);
+    p = __builtin_fma(p, z, DM_K(-1.0 / 27.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 25.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 23.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 21.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 19.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 17.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 15.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 13.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 11.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 9.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 7.0));
+    p = __builtin_fma(p, z, DM_K(1.0 / 5.0));
+    p = __builtin_fma(p, z, DM_K(-1.0 / 3.0));
+    p = __builtin_fma(p, z, DM_K(1.0));
     return base + u * p;
 }
 
