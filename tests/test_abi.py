@@ -56,6 +56,19 @@ def test_create_without_gpu_is_an_error_not_a_fallback(L):
         rayn_amd.Context(0)
 
 
+def test_bench_without_gpu_exits_loudly():
+    """bench.py has no CPU path either: without a GPU it stops with a message instead of timing the oracle."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no GPU visible" in (r.stderr + r.stdout)
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())  # and prints no result line
+
+
 def test_traced_sdf_transform_maps_to_the_hitable_fields():
     """EXTENSION plumbing (host logic, no GPU): TracedSDF.transform_seq -> rayn_hitable.center / animated / center_vel,
     and the default keeps the reference's zero, non-animated origin."""
