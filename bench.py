@@ -7,8 +7,8 @@ HBM.  The default workload is the configuration BASELINE.json's metric is quoted
 = configs[2]: 1920x1080, 1024 spp, 8 bounces, the reference's SDF fractal + homogeneous volume; the fractal is
 a MandelBox — the reference has no Mandelbulb); it fits one GPU (2.12 G paths, rendered in
 tile batches).  --workload c2 is configs[1] (256 spp, volumes off), bulb the added Mandelbulb DE.  N>1: the SAME
-frame is partitioned by tiles (rotating round-robin) across ranks and gathered to rank 0 with one grouped RCCL
-send/recv exchange (exact per-rank pixel counts, preallocated buffers) inside the timed region -> strong scaling.
+frame is partitioned by tiles (rotating round-robin) across ranks and gathered to rank 0 with ONE RCCL gather
+(preallocated buffers, per-rank blocks padded to the largest share) inside the timed region -> strong scaling.
 
   python bench.py --gpus 1 --steps 2 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -68,7 +68,9 @@ def main():
     # test aids for the N>1 path on a box with fewer GPUs than ranks (never used by the driver's launch)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo stages the gather through host memory)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks render on cuda:0 (RCCL refuses two ranks on one device: use with --backend gloo)")
-    ap.add_argument("--check-film", action="store_true", help="N>1: rank 0 re-renders the whole frame alone after the timed region and compares it bit for bit with the gathered film")
+    ap.add_argument("--check-film", action="store_true", help="rank 0 re-renders the whole frame alone after the timed region and compares it bit for bit with the gathered film")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barrier, all-reduce, FilmGather incl. rank 0's own block) even at "
+                    "world size 1: executes the RCCL path of the multi-GPU launch on a one-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,8 +94,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(device))
         else:
@@ -110,7 +114,7 @@ def main():
     ctx.set_fma_policy(args.fma_policy)
     d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
     film = rayn_amd.film.alloc_device_film(W, H, device)
-    gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo")) if world > 1 else None
+    gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo"), force=args.force_dist) if use_dist else None
 
     def step():
         ctx.render_device(p, d_tabs, film)
@@ -119,13 +123,13 @@ def main():
         return film
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def all_max(x):
+    def all_reduce(x, op):
         t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=op)
         return float(t.item())
 
     for _ in range(args.warmup):
@@ -136,10 +140,13 @@ def main():
         result = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        dt = all_max(dt)
+    stats = ctx.stats()
+    segments_per_step = stats["segments"]
+    if use_dist:
+        dt = all_reduce(dt, dist.ReduceOp.MAX)
+        segments_per_step = int(all_reduce(float(stats["segments"]), dist.ReduceOp.SUM))  # every rank's own share (exact below 2^53)
     film_check = None
-    if world > 1 and args.check_film and rank == 0:  # outside the timed region: the whole frame on this rank alone
+    if use_dist and args.check_film and rank == 0:  # outside the timed region: the whole frame on this rank alone
         p_full = rayn_amd.frame_params(W, H, samples, bounces)
         film_full = rayn_amd.film.alloc_device_film(W, H, device)
         ctx.render_device(p_full, d_tabs, film_full)
@@ -148,7 +155,6 @@ def main():
         del film_full
     paths_per_step = W * H * spp
     value = paths_per_step * args.steps / dt / 1e6
-    stats = ctx.stats()
 
     roofline = None
     roofline_hbm = None
@@ -264,16 +270,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "paths_per_step": paths_per_step, "tile": [p.tile_w, p.tile_h], "fma_policy": "unfused (reference default build)" if args.fma_policy == 0 else "fused (reference built with +fma)",
-                       "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one grouped RCCL send/recv of the owned pixels to rank 0 per frame" if world > 1 else "")},
+                       "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one RCCL gather of the owned pixels to rank 0 per frame" if use_dist else "")},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "kernel_ms": kernel_ms,
-            "segments_per_step": stats["segments"] * world if world > 1 else stats["segments"],
+            "segments_per_step": segments_per_step,
         }
+        out["config"]["build_variant"] = rayn_amd._lib.build_variant() or "product"
         if film_check is not None:
             out["film_check"] = film_check  # gathered film == single-rank film, bit for bit
-        if world > 1 and args.backend != "nccl":
+        if use_dist and args.backend != "nccl":
             out["config"]["parallelism"] += f" [TEST MODE: backend {args.backend}, gather staged through host memory" + (", all ranks on one GPU" if args.share_gpu else "") + "]"
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

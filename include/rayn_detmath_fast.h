@@ -12,14 +12,13 @@
  *   3. otherwise (about 3e-5 of the calls), and for every special case (NaN, inf, zero, huge or tiny arguments), evaluate the
  *      reference function itself.
  *
- * STATUS: an evaluated alternative, NOT what the shipped kernels use (they evaluate rayn_detmath.h directly; -DRAYN_FAST_DETMATH
- * switches them to this header).  It is correct - see the tests below - and halves the binary64 polynomial work.  First measurement
- * (r2, coefficients as plain literals): k_shade_setup went from 79 to ~125 VGPRs, 228 B of scratch per lane at the kernel's
- * 6-waves/SIMD register bound, 1.7x slower.  The cause was the compiler hoisting every coefficient of the fused steps into a vector
- * register pair (see DM_K in rayn_detmath.h); with the coefficients pinned to scalar registers the variant needs 79 VGPRs / 16 B of
- * scratch and k_shade_setup is 1.4 % FASTER than the shipped kernel (153.6 vs 155.7 ms per 1/8 share of config 3, bit-identical in
- * the fuzz run) - a gain of 0.2 % of the frame, which says the polynomial chains are not where the pinned functions spend their
- * time (range reduction, binary64 divisions and conversions are).  Not shipped in r2: measured after the round's evidence run.
+ * STATUS: what the kernels evaluate since r3 (rayn_amd/csrc/device_core.h calls dmf_*; the oracle keeps evaluating rayn_detmath.h, so
+ * every GPU parity test also checks this header).  History: with the coefficients as plain literals (r2) the compiler hoisted every
+ * coefficient of the fused steps into a vector register pair - k_shade_setup went from 79 to ~125 VGPRs, 228 B of scratch per lane
+ * at its 6-waves/SIMD register bound, 1.7x slower; with the coefficients pinned to scalar registers (DM_K in rayn_detmath.h) it needs
+ * 79 VGPRs / 16 B of scratch and k_shade_setup is 1.4 % faster than with rayn_detmath.h (153.6 vs 155.7 ms per 1/8 share of config 3).
+ * The small gain says the polynomial chains are not where the pinned functions spend their time (range reduction, binary64
+ * divisions and conversions are).
  *
  * The result is bit-identical to rayn_detmath.h by construction as long as EPS really bounds |d - R|.  The analytic
  * truncation bounds are stated per function; EPS is at least 3x larger.  tests/test_detmath.py checks on the CPU (this header compiles

@@ -196,7 +196,8 @@ int rayn_hip_create(int device, rayn_ctx** out);
  * tile goes to device (j + j / n) % n), scene and tables are replicated, every device renders its tiles with its own
  * streams, and each device other than devices[0] sends the pixels of its tiles to devices[0] with ONE peer copy over xGMI
  * (hipMemcpyPeerAsync of 10 floats per pixel) - the only data that crosses devices.  A device id may repeat (the entries
- * then share that GPU; used by the single-GPU tests).  rayn_hip_set_trace_tile is not supported on a multi-device ctx. */
+ * then share that GPU and split its memory budget; used by the single-GPU tests).  rayn_hip_set_trace_tile returns
+ * RAYN_ERR_INVALID_ARG on a multi-device ctx. */
 int rayn_hip_create_multi(const int* devices, int n_devices, rayn_ctx** out);
 int rayn_hip_device_count(const rayn_ctx* ctx); /* entries of the context (1 for rayn_hip_create) */
 void rayn_hip_destroy(rayn_ctx* ctx);
@@ -222,7 +223,9 @@ int rayn_hip_render_frame(rayn_ctx* ctx, const rayn_frame_params* p,
 /* Same, but every pointer is a DEVICE pointer on the ctx's GPU and the work is enqueued on
  * 'hip_stream' (a hipStream_t; NULL = the ctx's own stream), after everything already queued there.
  * The call is BLOCKING: it returns when the frame is complete (it waits once, at the end, to read the
- * frame statistics back; the depth loop itself never synchronises - queue sizes stay on the device).
+ * frame statistics back; queue sizes stay on the device and the depth loop of a frame with <= 8 bounces never synchronises -
+ * deeper ones read the queue size back every 4th depth from depth 8 on, to stop enqueueing depths for a batch whose paths have
+ * all terminated).
  * This is the entry the bench and the multi-GPU paths use. */
 int rayn_hip_render_frame_device(rayn_ctx* ctx, const rayn_frame_params* p,
                                  const float* d_samples_1d, const float* d_samples_2d,
@@ -278,6 +281,9 @@ int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy);
 /* sizeof() of the ABI structs as compiled: 0 world_desc, 1 frame_params, 2 stats, 3 hitable,
  * 4 material, 5 light, 6 camera — lets a binding verify its layout. */
 size_t rayn_hip_sizeof(int which);
+/* "" for the product build of the library; the VARIANT name of a `make variant` build (timing experiments: such a build is
+ * only ever loaded through RAYN_HIP_LIB + RAYN_HIP_ALLOW_VARIANT=1, and bench.py prints the name in its result line). */
+const char* rayn_hip_build_variant(void);
 
 /* Restrict the following renders to the listed tiles (indices in the reference's tile order, src/film.rs:399-427; duplicates
  * and out-of-range indices are an error); n = 0 clears the restriction.  While a subset is set tile_first/tile_step are

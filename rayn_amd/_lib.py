@@ -6,9 +6,27 @@ import subprocess
 
 from . import _abi
 
+
+class RaynHipError(RuntimeError):
+    pass
+
+
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-# RAYN_HIP_LIB: an alternative build of the same library (timing experiments, e.g. tools/ubench variants); default = the in-tree one
-LIB_PATH = os.environ.get("RAYN_HIP_LIB") or os.path.join(_CSRC, "librayn_hip.so")
+DEFAULT_LIB_PATH = os.path.join(_CSRC, "librayn_hip.so")
+
+
+def _lib_path():
+    """The in-tree product build.  RAYN_HIP_LIB names an alternative build of the same library (timing experiments: `make variant`)
+    and is honoured ONLY together with RAYN_HIP_ALLOW_VARIANT=1 - an experiment build can never be picked up silently; the
+    library reports its variant name (rayn_hip_build_variant, "" = product) and bench.py prints it."""
+    alt = os.environ.get("RAYN_HIP_LIB")
+    if not alt:
+        return DEFAULT_LIB_PATH
+    if os.environ.get("RAYN_HIP_ALLOW_VARIANT") != "1":
+        raise RaynHipError(f"RAYN_HIP_LIB={alt} is set but RAYN_HIP_ALLOW_VARIANT=1 is not: refusing to load a non-product build of librayn_hip.so")
+    return alt
+
+
 
 # every symbol include/rayn_hip.h declares
 EXPORTS = [
@@ -16,12 +34,8 @@ EXPORTS = [
     "rayn_hip_render_frame_device", "rayn_hip_get_stats", "rayn_sets_1d", "rayn_sets_2d", "rayn_build_rd_tables",
     "rayn_build_scramble", "rayn_build_fis_table", "rayn_build_fis_table_ex", "rayn_tile_count", "rayn_hip_set_profiling", "rayn_hip_get_eval_counts",
     "rayn_hip_set_batch_paths", "rayn_hip_set_workers", "rayn_hip_set_tile_subset", "rayn_hip_set_trace_tile", "rayn_hip_get_trace", "rayn_hip_fma_policy", "rayn_hip_set_fma_policy", "rayn_hip_sizeof", "rayn_hip_probe_sdf_dist",
-    "rayn_hip_probe_closest_hit", "rayn_hip_probe_occluded", "rayn_hip_probe_detmath",
+    "rayn_hip_probe_closest_hit", "rayn_hip_probe_occluded", "rayn_hip_probe_detmath", "rayn_hip_build_variant",
 ]
-
-
-class RaynHipError(RuntimeError):
-    pass
 
 
 def build(force=False):
@@ -37,6 +51,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        LIB_PATH = _lib_path()
         if not os.path.exists(LIB_PATH):
             raise RaynHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
@@ -85,5 +100,12 @@ def lib():
         L.rayn_hip_probe_closest_hit.argtypes = [vp, C.POINTER(_abi.FrameParams), C.c_uint32, fp, fp, fp, up, C.c_uint32]
         L.rayn_hip_probe_occluded.argtypes = [vp, C.POINTER(_abi.FrameParams), fp, fp, fp, C.c_uint32]
         L.rayn_hip_probe_detmath.argtypes = [vp, C.c_uint32, fp, fp, fp, C.c_uint32]
+        L.rayn_hip_build_variant.restype = C.c_char_p
+        L.rayn_hip_build_variant.argtypes = []
         _lib = L
     return _lib
+
+
+def build_variant():
+    """"" for the product build, else the name the library was built with (`make variant VARIANT=...`)."""
+    return lib().rayn_hip_build_variant().decode()

@@ -16,26 +16,10 @@
 #define RAYN_KNS rayn_p0
 #endif
 
-#if defined(RAYN_FAST_DETMATH) && !defined(RAYN_ABLATE_DETMATH)
-/* OPT-IN (make variant VFLAGS=-DRAYN_FAST_DETMATH): evaluate the pinned elementary functions through include/rayn_detmath_fast.h -
- * shorter fused polynomials + a rounding-safety test + the reference evaluation as the fallback; the same result bits as
- * rayn_detmath.h (checked on 8 M arguments per function on the CPU and through the device probe), about half the binary64
- * operations.  NOT the default: in k_shade_setup the variant needs ~125 VGPRs instead of 79 to stay out of scratch (228 B of
- * spills at the 6-waves/SIMD bound) and runs 1.7x SLOWER (c3 1/8 share 274 vs 163 ms; c2 30.2 vs 14.7 ms) - DESIGN.md section 4. */
-#define dm_expf(x) dmf_expf(x)
-#define dm_powf(x, y) dmf_powf(x, y)
-#define dm_sincosf(x, s, c) dmf_sincosf(x, s, c)
-#define dm_atan2f(y, x) dmf_atan2f(y, x)
-#define dm_tanf(x) dmf_tanf(x)
-#endif
-
-#ifdef RAYN_ABLATE_DETMATH /* TIMING EXPERIMENT ONLY (results are wrong): hardware approximations instead of the pinned f64-evaluated functions */
-#define dm_expf(x) __expf(x)
-#define dm_powf(x, y) __powf(x, y)
-#define dm_sincosf(x, s, c) __sincosf(x, s, c)
-#define dm_atan2f(y, x) atan2f(y, x)
-#define dm_tanf(x) __tanf(x)
-#endif
+// The pinned elementary functions are evaluated through include/rayn_detmath_fast.h (dmf_*): shorter fused polynomials on the
+// bit-identical reduced argument + a rounding-safety test + the rayn_detmath.h evaluation as the fallback (~3e-5 of the calls) -
+// the same result bits as rayn_detmath.h (tests/test_detmath.py on the CPU, the C-ABI probe on the device), about half the
+// binary64 operations.
 
 namespace RAYN_KNS {
 using namespace rayn;
@@ -47,19 +31,6 @@ RD float fmaxs(float a, float b) { return a > b ? a : b; } // a.max(b): maxps
 RD float fmins(float a, float b) { return a < b ? a : b; } // a.min(b): minps
 RD float signum(float x) { return x != x ? x : __builtin_copysignf(1.0f, x); }
 RD float muladd(float a, float b, float c) { return rayn_muladd(a, b, c); }
-// two binary32 values in an aligned register pair: element-wise *, + and fma compile to the packed VOP3P forms
-// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  EXPERIMENT, off by default: see RAYN_PACKED_FOLD in sdf_dist.
-typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef RAYN_PACKED_FOLD
-#define RAYN_PACKED_FOLD 0
-#endif
-RD v2f muladd2(v2f a, v2f b, v2f c) {
-#if RAYN_FMA_POLICY
-    return __builtin_elementwise_fma(a, b, c);
-#else
-    return a * b + c;
-#endif
-}
 RD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; } // sdfu Lerp
 
 constexpr float PI_F = 3.14159265358979323846f;
@@ -148,7 +119,7 @@ RD void concentric_circle_map(float u0, float u1, float* ox, float* oy) { // :20
     float r = mask ? a : b;
     float phi = mask ? phi1 : phi2;
     float s, c;
-    dm_sincosf(phi, &s, &c);
+    dmf_sincosf(phi, &s, &c);
     *ox = r * c;
     *oy = r * s;
 }
@@ -160,11 +131,11 @@ RD f3 cosine_weighted_in_hemisphere(float u0, float u1) { // :99-103
     return f3{x, y, z};
 }
 RD f3 cosine_power_weighted(float u0, float u1, float power) { // :106-113
-    float a = dm_powf(u0, 1.0f / (power + 1.0f));
+    float a = dmf_powf(u0, 1.0f / (power + 1.0f));
     float a2 = a * a;
     float b = sqrt_rn(1.0f - a2);
     float s, c;
-    dm_sincosf(2.0f * u1, &s, &c);
+    dmf_sincosf(2.0f * u1, &s, &c);
     return f3{b * c, b * s, a};
 }
 RD float f_schlick(float cosv, float f0) { // :122-124
@@ -260,11 +231,43 @@ RD float div_short(float n, float d) {
 RD float sdf_scale(const DHitable& h, float t0) { return h.scale_vel != 0.0f ? h.scale + h.scale_vel * t0 : h.scale; }
 
 // 'scale' = sdf_scale(h, t0) of the calling packet (h.scale itself in the reference's time-independent case)
+//
+// MandelBox::dist (src/sdf.rs:125-188), one fold iteration = box_fold, sphere_fold, scale + offset:
+//   box_fold     p = clamped(-l, l).mul_add(2, -p)
+//   sphere_fold  mul = max(1, R2 / max(r2min, r2));  p *= mul;  dr *= mul
+//                For r2 >= R2 (and for NaN) the quotient is <= 1, mul is exactly 1 and the multiplies are identities, so the
+//                block only matters for lanes with r2 < R2, where the quotient is >= 1: max(1, q) == q.  It runs under the
+//                folding lanes' exec mask (a plain per-lane 'if': v_cmp + s_and_saveexec + s_cbranch_execz, the branch taken
+//                only when NO lane of the wave folds).  A lane folds in 2.4-2.9 of the 12 iterations, SOME lane of a wave in
+//                9-11.7 of them; every other layout that was measured (wave-uniform branch, branch-free select, dense below
+//                a lane count, packed binary32) is slower - DESIGN.md section 4, tools/variants/README.md.
+//   scale+offset p = p.mul_add(s, p0);  dr = (-dr).mul_add(s, 1)
+// DIV is the quotient R2 / max(r2min, r2) (IEEE '/', div_nr or div_short, chosen by the host per object: DHitable::fast_div),
+// BOX the 2c - p of the box fold (mul_add per policy, or one fma where the product 2c is exact).
+#define RAYN_FOLD_ITER(DIV, BOX)                                          \
+    {                                                                     \
+        p.x = BOX(__builtin_amdgcn_fmed3f(p.x, nl, l), p.x);              \
+        p.y = BOX(__builtin_amdgcn_fmed3f(p.y, nl, l), p.y);              \
+        p.z = BOX(__builtin_amdgcn_fmed3f(p.z, nl, l), p.z);              \
+        const float r2 = mag_sq(p);                                       \
+        if (r2 < frs_eff) { /* not NaN on a folding lane: ONE raw v_max_f32 */ \
+            const float m = DIV(frs, vmax_raw(r2, mrs_v));                \
+            p.x *= m; p.y *= m; p.z *= m;                                 \
+            dr *= m;                                                      \
+        }                                                                 \
+        p.x = muladd(p.x, s, offset.x);                                   \
+        p.y = muladd(p.y, s, offset.y);                                   \
+        p.z = muladd(p.z, s, offset.z);                                   \
+        dr = muladd(-dr, s, 1.0f);                                        \
+    }
+#define RAYN_DIV_IEEE(a, b) ((a) / (b))
+#define RAYN_BOX_REF(c, q) muladd(c, 2.0f, -(q))
+// |c| <= |l| <= 2^60: the product 2c is exact, so ONE rounding (fma) == the reference's two (mul, add)
+#define RAYN_BOX_FMA(c, q) __builtin_fmaf(c, 2.0f, -(q))
+#define RAYN_FOLD_X4(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX)
 template <bool COUNT>
 RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
-#ifndef RAYN_COUNT_FOLDS
     if (COUNT) evals++;
-#endif
     if (h.sdf_kind == RAYN_SDF_MANDELBOX) {
         const f3 offset = p;
         float dr = 1.0f;
@@ -278,170 +281,29 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
         asm("" : "+v"(mrs_v));
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
-#ifdef RAYN_ABLATE_FOLD /* timing experiment only (wrong results): never enter the sphere-fold block */
-#define RAYN_FOLD_ENABLE false
-#else
-#define RAYN_FOLD_ENABLE true
-#endif
-/* Layout hint for the wave-uniform fold test: 1 = the block is laid out inline (fall through when some lane folds, one taken
- * branch when none does), 0 = out of line (two taken branches whenever some lane folds - which is 94 % of the iterations). */
-#ifndef RAYN_FOLD_LIKELY
-#define RAYN_FOLD_LIKELY 0
-#endif
-#ifndef RAYN_FOLD_PLAIN_IF
-#define RAYN_FOLD_PLAIN_IF 1
-#endif
-#ifndef RAYN_FOLD_BRANCHFREE
-#define RAYN_FOLD_BRANCHFREE 0
-#endif
-/* When fewer than this many lanes of the wave fold in an iteration, the block runs on all 64 lanes with a select instead of
- * under the folding lanes' exec mask (0 = always exec-masked).  Same values either way: non-folding lanes multiply by 1.0. */
-#ifndef RAYN_FOLD_DENSE_BELOW
-#define RAYN_FOLD_DENSE_BELOW 0
-#endif
-#ifdef RAYN_COUNT_FOLDS /* experiment: the instrumented kernels count sphere-fold block entries (per active lane) instead of evaluations */
-#define RAYN_FOLD_COUNT_HOOK if (COUNT && fold) evals++;
-#else
-#define RAYN_FOLD_COUNT_HOOK
-#endif
-#define RAYN_FOLD_ITER(DIV, BOX)                                                                  \
-        {                                                                                     \
-            /* box_fold: clamped(-l, l).mul_add(2, -p) */                                     \
-            p.x = BOX(__builtin_amdgcn_fmed3f(p.x, nl, l), p.x);                              \
-            p.y = BOX(__builtin_amdgcn_fmed3f(p.y, nl, l), p.y);                              \
-            p.z = BOX(__builtin_amdgcn_fmed3f(p.z, nl, l), p.z);                              \
-            /* sphere_fold: mul = max(1, R2 / max(r2min, r2)).  For r2 >= R2 (and for NaN) the quotient  \
-               is <= 1, mul is exactly 1 and the multiplies are identities, so the block only matters for  \
-               lanes with r2 < R2, where the quotient is >= 1: max(1, q) == q.  Measured                  \
-               (-DRAYN_COUNT_FOLDS): a lane folds in 2.4-2.9 of the 12 iterations, but SOME lane of the   \
-               wave folds in 9-11.7 of them, so the block is part of nearly every iteration.  Layouts      \
-               measured on a c3 1/8 share (k_shadow1 / k_extend1 ms): plain per-lane 'if' 755 / 120.5      \
-               (shipped: v_cmp + s_and_saveexec + s_cbranch_execz, the branch taken only when NO lane      \
-               folds); wave-uniform test (ballot -> scalar branch) with the block out of line 759 / 122.2  \
-               (r1's choice: two taken branches whenever some lane folds), the same hinted likely 799 /    \
-               128 (the compiler rebuilds the ballot with two more VALU instructions); branch-free select  \
-               slower still (r1). */                                                                       \
-            const float r2 = mag_sq(p);                                                       \
-            const bool fold = RAYN_FOLD_ENABLE && r2 < frs_eff;                               \
-            if (RAYN_FOLD_BRANCHFREE) {                                                       \
-                /* no control flow at all: every lane divides, non-folding lanes select 1.0 */ \
-                const float q = DIV(frs, vmax_raw(r2, mrs_v));                                  \
-                const float m = fold ? q : 1.0f;                                              \
-                p.x *= m; p.y *= m; p.z *= m;                                                 \
-                dr *= m;                                                                      \
-            } else if (RAYN_FOLD_PLAIN_IF) {                                                  \
-                /* per-lane 'if': v_cmp + s_and_saveexec + s_cbranch_execz, the branch taken only when NO lane folds */ \
-                if (fold) {                                                                   \
-                    RAYN_FOLD_COUNT_HOOK                                                      \
-                    const float m = DIV(frs, vmax_raw(r2, mrs_v));                              \
-                    p.x *= m; p.y *= m; p.z *= m;                                             \
-                    dr *= m;                                                                  \
-                }                                                                             \
-            } else {                                                                          \
-                const unsigned long long fold_lanes = __builtin_amdgcn_ballot_w64(fold);      \
-                if (__builtin_expect(fold_lanes != 0, RAYN_FOLD_LIKELY)) {                    \
-                    RAYN_FOLD_COUNT_HOOK                                                      \
-                    if (RAYN_FOLD_DENSE_BELOW > 0 && __builtin_popcountll(fold_lanes) < RAYN_FOLD_DENSE_BELOW) { \
-                        /* few folding lanes: run the block on ALL lanes and select (see RAYN_FOLD_DENSE_BELOW) */ \
-                        const float q = DIV(frs, vmax_raw(r2, mrs_v));                          \
-                        const float m = fold ? q : 1.0f;                                      \
-                        p.x *= m; p.y *= m; p.z *= m;                                         \
-                        dr *= m;                                                              \
-                    } else if (fold) {                                                        \
-                        /* r2 is not NaN on a folding lane: ONE raw v_max_f32 (fmaxf / med3 lower to three, two of  \
-                           them canonicalising no-ops) */                                     \
-                        const float m = DIV(frs, vmax_raw(r2, mrs_v));                          \
-                        p.x *= m; p.y *= m; p.z *= m;                                         \
-                        dr *= m;                                                              \
-                    }                                                                         \
-                }                                                                             \
-            }                                                                                 \
-            p.x = muladd(p.x, s, offset.x);                                                   \
-            p.y = muladd(p.y, s, offset.y);                                                   \
-            p.z = muladd(p.z, s, offset.z);                                                   \
-            dr = muladd(-dr, s, 1.0f);                                                        \
-        }
-#define RAYN_DIV_IEEE(a, b) ((a) / (b))
-#define RAYN_BOX_REF(c, q) muladd(c, 2.0f, -(q))
-        // |c| <= |l| <= 2^60: the product 2c is exact, so ONE rounding (fma) == the reference's two (mul, add)
-#define RAYN_BOX_FMA(c, q) __builtin_fmaf(c, 2.0f, -(q))
         if (h.fast_div == 2) {
-#if RAYN_PACKED_FOLD
-            // EXPERIMENT (-DRAYN_PACKED_FOLD=1; measured r2, not shipped): the same iteration on PACKED binary32 operations
-            // (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two IEEE operations per instruction).  The state is two register
-            // pairs, (x, y) and (z, dr): the box fold's 2c - p, the squares, the sphere fold's four multiplies and the
-            // scale + offset step are 2-wide; the clamps (v_med3_f32) and the quotient have no packed form.  Every lane-level
-            // operation and its operands are the ones of RAYN_FOLD_ITER - (-dr)*s is computed as dr*(-s), the same product -
-            // and the film is bit-identical (100 GPU tests, 150 fuzz scenes).  The compiler emits exactly the intended 15
-            // VALU instructions per iteration instead of 21 - and the kernels are SLOWER: c3 1/8 share k_shadow1 885 ms vs
-            // 771 ms, k_extend1 138 vs 123 ms.  A packed binary32 instruction costs this code more than the two plain ones
-            // it replaces: the 157 TFLOP/s vector peak is not reachable by packing a dependent scalar chain.
-            v2f pxy = {p.x, p.y}, pzd = {p.z, 1.0f};
-            const v2f oxy = pxy, ozd = pzd, s2 = {s, s}, sn2 = {s, -s}, two2 = {2.0f, 2.0f};
-#define RAYN_FOLD_ITER2                                                                           \
-            {                                                                                     \
-                const v2f cxy = {__builtin_amdgcn_fmed3f(pxy.x, nl, l), __builtin_amdgcn_fmed3f(pxy.y, nl, l)}; \
-                const float cz = __builtin_amdgcn_fmed3f(pzd.x, nl, l);                           \
-                pxy = __builtin_elementwise_fma(cxy, two2, -pxy);                                 \
-                pzd.x = __builtin_fmaf(cz, 2.0f, -pzd.x);                                         \
-                float r2;                                                                         \
-                if (RAYN_FMA_POLICY) r2 = muladd(pxy.x, pxy.x, muladd(pxy.y, pxy.y, pzd.x * pzd.x)); \
-                else { const v2f q = pxy * pxy; r2 = q.x + (q.y + pzd.x * pzd.x); }               \
-                const bool fold = RAYN_FOLD_ENABLE && r2 < frs_eff;                               \
-                const unsigned long long fold_lanes = __builtin_amdgcn_ballot_w64(fold);          \
-                if (__builtin_expect(fold_lanes != 0, RAYN_FOLD_LIKELY)) {                                       \
-                    RAYN_FOLD_COUNT_HOOK                                                          \
-                    if (fold) {                                                                   \
-                        const float m = div_short(frs, vmax_raw(r2, mrs_v));                        \
-                        const v2f m2 = {m, m};                                                    \
-                        pxy = pxy * m2; pzd = pzd * m2;                                           \
-                    }                                                                             \
-                }                                                                                 \
-                pxy = muladd2(pxy, s2, oxy);                                                      \
-                pzd = muladd2(pzd, sn2, ozd);                                                     \
-            }
             uint32_t i = 0;
-            if (h.iterations == 12) { // the shipped iteration count (src/setup.rs:44), fully unrolled
-                RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2
-                RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2
+            if (h.iterations == 12) { // the shipped iteration count (src/setup.rs:44), fully unrolled: 2 % over the rolled loop
+                RAYN_FOLD_X4(div_short, RAYN_BOX_FMA) RAYN_FOLD_X4(div_short, RAYN_BOX_FMA) RAYN_FOLD_X4(div_short, RAYN_BOX_FMA)
                 i = 12;
             }
-            for (; i + 4 <= h.iterations; i += 4) { RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 RAYN_FOLD_ITER2 }
-            for (; i < h.iterations; i++) RAYN_FOLD_ITER2
-#undef RAYN_FOLD_ITER2
-            p = f3{pxy.x, pxy.y, pzd.x};
-            dr = pzd.y;
-#else
-            // unrolled by 4 by hand (the ballot is a convergent operation, which stops the loop unroller): the taken
-            // back-edge of the rolled loop costs about as much as four VALU operations per iteration
-            uint32_t i = 0;
-            if (h.iterations == 12) { // the shipped iteration count (src/setup.rs:44), fully unrolled: another 2 %
-                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
-                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
-                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
-                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
-                i = 12;
-            }
-            for (; i + 4 <= h.iterations; i += 4) {
-                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
-                RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
-            }
+            for (; i + 4 <= h.iterations; i += 4) { RAYN_FOLD_X4(div_short, RAYN_BOX_FMA) }
             for (; i < h.iterations; i++) RAYN_FOLD_ITER(div_short, RAYN_BOX_FMA)
-#endif
         } else if (h.fast_div) {
             for (uint32_t i = 0; i < h.iterations; i++) RAYN_FOLD_ITER(div_nr, RAYN_BOX_FMA)
         } else {
             for (uint32_t i = 0; i < h.iterations; i++) RAYN_FOLD_ITER(RAYN_DIV_IEEE, RAYN_BOX_REF)
         }
-#undef RAYN_FOLD_ITER
-#undef RAYN_DIV_IEEE
-#undef RAYN_BOX_REF
-#undef RAYN_BOX_FMA
         return mag(p) / __builtin_fabsf(dr);
     }
     if (h.sdf_kind == RAYN_SDF_MANDELBULB) return mandelbulb_dist(p, h.iterations);
     return mag(p) - h.sdf_radius;
 }
+#undef RAYN_FOLD_X4
+#undef RAYN_FOLD_ITER
+#undef RAYN_DIV_IEEE
+#undef RAYN_BOX_REF
+#undef RAYN_BOX_FMA
 
 // hit threshold closure, src/film.rs:540-551 (Camera::half_pixel_size_at src/camera.rs:116,210,282)
 struct Thr { float k; bool constant; };
@@ -603,7 +465,7 @@ RD void light_sample(const DLight& L, float u0, float u1, f3 p, f3* out_point, f
     float cos_alpha = (dist_sq + r2 - ds * ds) / (2.0f * dist * L.rad);
     float sin_alpha = sqrt_rn(fmaxs(0.0f, 1.0f - cos_alpha * cos_alpha));
     float sin_phi, cos_phi;
-    dm_sincosf(phi, &sin_phi, &cos_phi);
+    dmf_sincosf(phi, &sin_phi, &cos_phi);
     f3 offset = basis.c0 * sin_alpha * cos_phi + basis.c1 * sin_alpha * sin_phi + basis.c2 * cos_alpha;
     *out_point = L.pos + offset * L.rad;
     *out_pdf = 1.0f / (TWO_PI_F * (1.0f - cos_theta_max)); // uniform_cone_pdf
@@ -612,9 +474,9 @@ RD void light_sample_volume(const DLight& L, float sample, f3 ray_o, f3 ray_d, f
     float delta = dot(L.pos - ray_o, ray_d);
     f3 closest_point = ray_o + delta * ray_d;
     float d = mag(closest_point - L.pos);
-    float theta_a = dm_atan2f(-delta, d);
-    float theta_b = dm_atan2f(max_distance - delta, d);
-    float t = d * dm_tanf(lerpf(theta_a, theta_b, sample));
+    float theta_a = dmf_atan2f(-delta, d);
+    float theta_b = dmf_atan2f(max_distance - delta, d);
+    float t = d * dmf_tanf(lerpf(theta_a, theta_b, sample));
     *out_dist = delta + t;
     *out_pdf = d / ((theta_b - theta_a) * muladd(d, d, t * t));
 }
@@ -627,7 +489,7 @@ RD f3 bsdf_f(const DMaterial& m, f3 arg0, f3 arg1, f3 n) {
         float dt = fmaxs(0.0f, dot(arg0, n));
         float fresnel = f_schlick(dt, 0.04f);
         f3 half = normalized(arg1 + arg0);
-        float cos_alpha = dm_powf(fmaxs(0.0f, dot(half, n)), m.exponent);
+        float cos_alpha = dmf_powf(fmaxs(0.0f, dot(half, n)), m.exponent);
         float spec_factor = cos_alpha * (m.exponent + 2.0f) / (2.0f * PI_F);
         f3 spec_f = f3{1.0f, 1.0f, 1.0f} * spec_factor * fresnel;
         f3 diffuse_f = m.a / PI_F * (1.0f - fresnel);
@@ -657,7 +519,7 @@ RD Scatter bsdf_scatter(const DMaterial& m, f3 wo, f3 normal, const Basis& basis
         f3 reflection = reflected(wo, normal);
         Basis rb = orthonormal_basis(reflection);
         f3 spec_bounce = normalized(mul(rb, spec_sample));
-        float cos_alpha_pow = fmaxs(dm_powf(spec_sample.z, m.exponent), EPSILON_F);
+        float cos_alpha_pow = fmaxs(dmf_powf(spec_sample.z, m.exponent), EPSILON_F);
         float spec_pdf = (m.exponent + 1.0f) / TWO_PI_F * cos_alpha_pow;
         float spec_coeff = (m.exponent + 2.0f) / TWO_PI_F * cos_alpha_pow;
         if (dot(normal, spec_bounce) < 0.0f) spec_coeff = 0.0f;

@@ -37,8 +37,10 @@ struct DScene {
     float time_start, time_range, detail_scale, t_max, ndc_x, ndc_y;
 };
 
-// One 16x16 (clamped) film tile of the current batch.
-struct DTile { uint32_t x0, y0, ew, eh; uint32_t pool_base, n_paths; uint32_t _pad[2]; };
+// One 16x16 (clamped) film tile of the current batch.  film_packed != 0: the resolve writes the tile's pixels at
+// [film_base + local pixel] of a PLANAR film that holds only the owned tiles (multi-device peers, rayn_hip.hip render_multi:
+// the buffer that crosses xGMI) instead of at (x, y) of a full-resolution film.
+struct DTile { uint32_t x0, y0, ew, eh; uint32_t pool_base, n_paths; uint32_t film_base, film_packed; };
 
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
 constexpr uint32_t OBJ_NONE = 0xFFu;

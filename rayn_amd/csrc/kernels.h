@@ -50,7 +50,8 @@ struct DCtl {
     uint32_t head_extend;  // persistent-kernel queue heads, reset on device between uses
     uint32_t job_count;    // pending shadow segments of this depth (k_shadow_list)
     uint32_t head_shadow;
-    uint32_t _pad;
+    uint32_t overflow;     // set by k_tile_prefix when a stage's output would not fit its queue (bit 0 bin, bit 1 repack): the scatter is
+                           // skipped, the stage's size becomes 0 and the host reports an internal error at the end of the share
     // statistics of the whole frame share (read back once, at the end)
     unsigned long long segments, shaded_slots, entries_sum, next_sum, shadow_jobs, _pad2;
 };
@@ -71,11 +72,7 @@ struct Tuning {
     uint32_t refill_min_shadow = 8;
     uint32_t prefetch_min_extend = 32;    // fast path: lanes without a spare ray before the bulk queue fetch
     uint32_t prefetch_min_shadow = 32;
-    uint32_t ablate = 0;                  // timing-only debug mask for k_shade_setup (see the kernel)
     bool fast_path = true;                // single-SDF specialisations k_extend1 / k_shadow1
-    bool shadow_scan = false;             // k_shadow1 finds the pending segments itself instead of consuming k_shadow_list's job list; measured
-                                          // SLOWER (c3 1/8 share: 935.8 ms vs 907.2 + 17.3 for the list; c2: 100.8 vs 96.5 ms) - kept as an option
-    bool setup_stride = false;            // k_shade_setup as a grid-stride loop (true) or one slot per thread over the upper-bound grid
 };
 
 // sample tables: the reference layout (src/sampler.rs:11-15) + a per-(depth, sample) packed copy built at
@@ -103,7 +100,7 @@ struct Tables {
                           uint32_t* tile_valid, uint32_t* tile_cls_cnt);                            \
     void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base, \
                             uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt, \
-                            uint32_t* tile_cls_base);                                               \
+                            uint32_t* tile_cls_base, uint32_t cap_groups);                          \
     void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base, \
                             const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles, \
                             const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const uint32_t* tile_cls_base, const DCtl* ctl); \
@@ -113,8 +110,8 @@ struct Tables {
     void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile, \
                                 const uint32_t* tile_out_base, uint32_t max_slots, uint32_t* qn, uint32_t n_tiles, const uint32_t* tile_total, \
                                 const DCtl* ctl);                                                   \
-    void launch_tile_pixels(hipStream_t s, bool pack, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha, \
-                            float* background, float* normal, float* packed);                       \
+    void launch_unpack_tiles(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha, \
+                             float* background, float* normal, const float* packed, size_t packed_pixels); \
     void launch_batch_setup(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t* pgrp_tile, uint32_t* tgb, uint32_t* tgc); \
     void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool, \
                         float* out_color, float* out_alpha, float* out_background, float* out_normal); \

@@ -20,6 +20,10 @@
 #include "device_core.h"
 #include "kernels.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "kernels.hip is written for gfx950 (MI355X): k_resolve_big / k_resolve_huge use 64 KB / 130 KB of the CU's 160 KB LDS"
+#endif
+
 namespace RAYN_KNS {
 
 RD uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -237,7 +241,6 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
     bool exhausted = false, endgame = false;
-    uint32_t trips64 = 0; (void)trips64;
     // current ray
     bool c_has = false, first = false, nan = false;
     uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0, evals = 0;
@@ -309,9 +312,6 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
             if (exhausted) break;
             continue;
         }
-#ifdef RAYN_COUNT_TRIPS
-        if (COUNT && lane == 0) trips64 += 64;
-#endif
         if (c_has) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
             const f3 p = first ? o : muladd3(d, t, o);
             const float dist = sdf_dist<COUNT>(h, p, evals, c_scale);
@@ -336,9 +336,6 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
             }
         }
     }
-#ifdef RAYN_COUNT_TRIPS
-    evals = trips64;
-#endif
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
@@ -434,7 +431,7 @@ __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const ui
                                                        const uint32_t* __restrict__ tile_valid, uint32_t* __restrict__ tile_out_base,
                                                        uint32_t* __restrict__ out_grp_begin, uint32_t* __restrict__ out_grp_count,
                                                        DCtl* __restrict__ ctl, int stage, uint32_t nclass, uint32_t pad,
-                                                       const uint32_t* __restrict__ tile_cls_cnt, uint32_t* __restrict__ tile_cls_base) {
+                                                       const uint32_t* __restrict__ tile_cls_cnt, uint32_t* __restrict__ tile_cls_base, uint32_t cap_groups) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_vsum[16];
     __shared__ uint32_t s_run, s_valid;
@@ -481,6 +478,7 @@ __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const ui
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        if (s_run > cap_groups) { ctl->overflow |= 1u << stage; s_run = 0; s_valid = 0; } // cannot happen by the host's sizing; never write past a queue
         if (stage == 0) {
             ctl->entries_sum += (unsigned long long)ctl->q_groups << 6;
             ctl->b_groups = s_run; ctl->b_valid = s_valid;
@@ -521,6 +519,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(uint32_t nclass, const uint
                                                       const uint32_t* __restrict__ tile_out_base, const DCtl* __restrict__ ctl,
                                                       uint32_t* __restrict__ bq, uint32_t n_tiles, const uint32_t* __restrict__ tile_cls_cnt,
                                                       const uint32_t* __restrict__ tile_total, const uint32_t* __restrict__ tile_cls_base) {
+    if (ctl->overflow) return;
     write_tile_padding(n_tiles, nclass, 4, tile_cls_cnt, tile_total, tile_out_base, bq);
     const uint32_t n_entries = ctl->q_groups << 6;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -559,6 +558,7 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
                                                           const uint32_t* __restrict__ grp_base, const uint32_t* __restrict__ grp_tile,
                                                           const uint32_t* __restrict__ tile_out_base, const DCtl* __restrict__ ctl,
                                                           uint32_t* __restrict__ qn, uint32_t n_tiles, const uint32_t* __restrict__ tile_total) {
+    if (ctl->overflow) return;
     write_tile_padding(n_tiles, 1, 1, nullptr, tile_total, tile_out_base, qn);
     const uint32_t n_slots = ctl->b_groups << 6;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -604,21 +604,19 @@ constexpr uint32_t VOL_MEMO_LIGHTS = 7; // per-light volume terms memoised in LD
 #ifndef RAYN_SETUP_WAVES
 #define RAYN_SETUP_WAVES 6 // waves per SIMD the register budget of k_shade_setup is set for (80 VGPRs)
 #endif
-// STRIDE: grid-stride loop over the slots (fixed grid) instead of one slot per thread with a grid sized for the batch's upper
-// bound (surplus blocks exit at once).  Both take the slot count from the control block; which one is faster is a
-// register-pressure question (the loop carries j and the count across a body that already spills) - see Tuning::setup_stride.
-template <bool COUNT, bool STRIDE>
+// One slot per thread over a grid sized for the batch's upper bound (surplus blocks exit at once; a grid-stride loop carries
+// j and the count across a body that already spills: +44 B of scratch, 22 % slower).
+template <bool COUNT>
 __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                       uint32_t depth, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl, Pool pool, Nee nee,
-                                                      uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt, uint32_t ablate,
+                                                      uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt,
                                                       unsigned long long* __restrict__ evals_out) {
-    // 'ablate' is a TIMING-ONLY debug mask (RAYN_HIP_ABLATE; results are wrong when non-zero): 1 no normal
-    // estimation, 2 no surface NEE, 4 no BSDF scatter, 8 no sphere occlusion tests, 16 no BSDF::f
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
     const uint32_t n_slots = ctl->b_groups << 6;
     uint32_t evals = 0;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_slots; j += gridDim.x * blockDim.x) { // whole waves: n_slots % 64 == 0
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_slots) return; // whole waves: n_slots % 64 == 0
     const uint32_t P = bq[j];
     const bool valid = P != INVALID;
     const uint32_t spp = sc.spp, nl = sc.n_lights, VM = sc.vm;
@@ -701,10 +699,10 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
         } else { // src/sdf.rs:85-101
             Thr th = make_thr(sc, depth);
             float hps = fmaxs(0.0001f, sc.detail_scale * thr_at(th, t));
-            normal = (ablate & 1u) ? f3{0.0f, 1.0f, 0.0f} : sdf_normal<COUNT>(h, point - sphere_center(h, t0), hps, evals, sdf_scale(h, t0));
+            normal = sdf_normal<COUNT>(h, point - sphere_center(h, t0), hps, evals, sdf_scale(h, t0));
             offset_by = hps;
         }
-        vol_T = sc.has_extinct ? dm_expf(-sc.rho_t * t) : 1.0f;
+        vol_T = sc.has_extinct ? dmf_expf(-sc.rho_t * t) : 1.0f;
         receives = sc.m[h.material].receives_light != 0;
         rad = rad + bsdf_le(sc.m[h.material], -d) * thr * vol_T;
         pool.col0[P] = make_float4(rad.x, rad.y, rad.z, c0.w); // throughput.r stays: k_shade_finish needs the old one
@@ -713,7 +711,7 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
     const DMaterial& mat = sc.m[sc.h[obj].material];
     const f3 wo = -d;
     // ---- surface NEE, surface_sample_one_light src/integrator.rs:207-240
-    const bool do_surf = valid && receives && nl > 0 && !(ablate & 2u);
+    const bool do_surf = valid && receives && nl > 0;
     {
         if (do_surf) flags |= 2u;
         for (uint32_t i = 0; i < 4; i++) {
@@ -734,15 +732,15 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
                 // light below the horizon: bsdf.f(..) * 0 is +0 whenever f is finite, which it is for finite
                 // inputs with a non-degenerate half vector -> skip the pow/normalize of BSDF::f (bit-identical)
                 if (cosw == 0.0f && ndw == ndw && mag_sq(wo + wi) > 0.0f) f = f3{0.0f, 0.0f, 0.0f};
-                else f = (ablate & 16u) ? f3{0.1f, 0.1f, 0.1f} * cosw : bsdf_f(mat, wo, wi, normal) * cosw;
-                float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dist) : 1.0f;
+                else f = bsdf_f(mat, wo, wi, normal) * cosw;
+                float tr = sc.has_extinct ? dmf_expf(-sc.rho_t * dist) : 1.0f;
                 f3 x = L.emission * f * tr;
                 nee.x[(i * 3 + 0) * cap + j] = x.x; nee.x[(i * 3 + 1) * cap + j] = x.y; nee.x[(i * 3 + 2) * cap + j] = x.z;
                 nee.pdf[i * cap + j] = pdf;
                 uint8_t vis = 1;
                 // x == 0 (light below the horizon): (x*occluded)/pdf is the same zero for occluded 0 or 1 -> no test needed
                 if (!all_zero(x)) {
-                    if (!(ablate & 8u) && !spheres_visible(occlude_point, end_point)) vis = 0;
+                    if (!spheres_visible(occlude_point, end_point)) vis = 0;
                     else if (scene_has_sdf) { vis = 2; park_job(i, occlude_point, end_point); }
                 }
                 nee.vis[i * cap + j] = vis;
@@ -765,7 +763,7 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
                 float vd = 0.0f, vp = 0.0f, va = 1.0f;
                 if (do_vol) {
                     light_sample_volume(sc.l[li], vsample, o, d, t, &vd, &vp);
-                    va = sc.has_extinct ? dm_expf(-sc.rho_t * vd) : 1.0f;
+                    va = sc.has_extinct ? dmf_expf(-sc.rho_t * vd) : 1.0f;
                 }
                 s_vol[(li * 3 + 0) * 256 + threadIdx.x] = vd;
                 s_vol[(li * 3 + 1) * 256 + threadIdx.x] = vp;
@@ -787,14 +785,14 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
                         vaux = s_vol[(li * 3 + 2) * 256 + threadIdx.x];
                     } else {
                         light_sample_volume(L, vsample, o, d, t, &vdist, &vpdf);
-                        vaux = sc.has_extinct ? dm_expf(-sc.rho_t * vdist) : 1.0f;
+                        vaux = sc.has_extinct ? dmf_expf(-sc.rho_t * vdist) : 1.0f;
                     }
                     f3 sp = o + d * vdist;
                     f3 end_point; float lpdf;
                     light_sample(L, u0, u1, sp, &end_point, &lpdf);
                     float dl = mag(end_point - sp);
                     float f = 1.0f / (4.0f * PI_F);
-                    float tr = sc.has_extinct ? dm_expf(-sc.rho_t * dl) : 1.0f;
+                    float tr = sc.has_extinct ? dmf_expf(-sc.rho_t * dl) : 1.0f;
                     (void)f; // x = L.emission * f * tr is rebuilt by k_shade_finish from the light index and tr (same operations, same bits)
                     nee.vtr[(s - 4) * cap + j] = tr;
                     nee.pdf[s * cap + j] = vpdf * lpdf;
@@ -815,8 +813,7 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
             const Basis basis = orthonormal_basis(normal);
             const float4 rb = rec[4 + 2 * VM]; // comps 8+8*VM .. +3
             float s3 = s1(3), s4 = s1(4);
-            Scatter se = (ablate & 4u) ? Scatter{normal, f3{0.3f, 0.3f, 0.3f}, 1.0f} : bsdf_scatter(mat, wo, normal, basis, s3, dm_fractf(rb.x + scr), dm_fractf(rb.y + scr), dm_fractf(rb.z + scr),
-                                      dm_fractf(rb.w + scr));
+            Scatter se = bsdf_scatter(mat, wo, normal, basis, s3, dm_fractf(rb.x + scr), dm_fractf(rb.y + scr), dm_fractf(rb.z + scr), dm_fractf(rb.w + scr));
             float ndl = __builtin_fabsf(dot(se.wi, normal));
             f3 nthr = thr * vol_T * se.f * ndl / se.pdf;
             float rr = 0.0f;
@@ -846,8 +843,6 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
     alive[j] = is_alive ? 1 : 0;
     uint64_t m = __ballot(is_alive);
     if (lane == 0) bgrp_cnt[j >> 6] = (uint8_t)__popcll(m);
-    if (!STRIDE) break;
-    } // grid-stride loop
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
@@ -1001,34 +996,20 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
 }
 
 // Fast path of k_shadow for scenes with exactly one TracedSDF: uniform SDF parameters, and a
-// prefetched NEXT segment per lane (see k_extend1).
-// SCAN (Tuning::shadow_scan, OFF by default - measured 1-4 % slower than list + march, the window logic and its 8 extra VGPRs
-// cost the hot loop more than the separate pass): the kernel finds its jobs itself.  Instead of consuming the dense list
-// k_shadow_list builds (one more pass over all NS x n_slots visibility bytes + 4 B per job written and read back: 1.4 % of a
-// config-3 frame), a wave walks the (sample, slot)
-// id space in 64-id windows: one coalesced load of the visibility bytes, a ballot of the pending ones, and the lanes that
-// need a segment take the window's pending ids in order - the k-th needy lane gets the k-th pending id, matched through a
-// 64-entry LDS table indexed by rank (one ds_write + one ds_read per window).  Ids are handed out in chunks like list
-// entries were; results are written by id, so nothing depends on which lane marches which segment.
-template <bool COUNT, bool SCAN>
-__global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, DCtl* __restrict__ ctl, uint32_t ns,
+// prefetched NEXT segment per lane (see k_extend1).  (A variant that scans the visibility bytes itself instead of consuming
+// k_shadow_list's job list was measured 1-4 % slower - window logic + 8 VGPRs in the hot loop; tools/variants/README.md.)
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, DCtl* __restrict__ ctl,
                                                   uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
-    __shared__ uint32_t s_pick[4][64];
     const DScene& sc = *scp;
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t n_slots = ctl->b_groups << 6;
-    const uint32_t n_jobs = SCAN ? ns * n_slots : ctl->job_count, max_vis = sc.max_vis_marches; // SCAN: ids, not jobs
+    const uint32_t lane = lane_id();
+    const uint32_t n_jobs = ctl->job_count, max_vis = sc.max_vis_marches;
     uint32_t* const head = &ctl->head_shadow;
-    if (!SCAN && blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
-    // SCAN: the current 64-id window (wave-uniform): pending ids not handed out yet, and the [sample*cap + slot] ref of its id 0
-    uint64_t win_mask = 0;
-    uint32_t win_ref = 0, win_s = 0, win_off = 0, taken = 0;
-    (void)s_pick; (void)wave; (void)win_ref; (void)win_s; (void)win_off; (void)taken;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
     const DHitable h = sc.h[ks];
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
     uint32_t cur = 0, end = 0;
     bool exhausted = false, endgame = false;
-    uint32_t trips64 = 0; (void)trips64;
     bool c_has = false, first = false, nan = false, n_has = false;
     uint32_t ref = 0, n_ref = 0, m = 0, evals = 0;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
@@ -1043,7 +1024,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             for (;;) {
                 const uint64_t need = endgame ? __ballot(!n_has && !c_has) : __ballot(!n_has);
                 if (need == 0) break;
-                if (cur == end && (!SCAN || win_mask == 0)) {
+                if (cur == end) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(head, CHUNK);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -1051,42 +1032,22 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                     cur = base;
                     end = min(base + CHUNK, n_jobs);
                     endgame = n_jobs - base < ENDGAME_ENTRIES;
-                    if (SCAN) { win_s = base / n_slots; win_off = base - win_s * n_slots; } // one division per chunk of 256 ids
                 }
-                uint32_t rank = mbcnt(need), avail = end - cur;
-                bool take = ((need >> lane) & 1ull) && rank < avail;
-                if (SCAN) {
-                    if (win_mask == 0) { // next 64-id window of the chunk (n_slots % 64 == 0: a window never straddles samples)
-                        win_ref = (uint32_t)(win_s * nee.cap) + win_off;
-                        win_mask = __ballot(nee.vis[win_ref + lane] == 2);
-                        cur += 64; win_off += 64;
-                        if (win_off == n_slots) { win_off = 0; win_s++; }
-                        if (win_mask == 0) continue;
-                    }
-                    const uint32_t n_serve = min((uint32_t)__popcll(need), (uint32_t)__popcll(win_mask));
-                    const uint32_t prank = mbcnt(win_mask);
-                    const bool give = ((win_mask >> lane) & 1ull) && prank < n_serve;
-                    if (give) s_pick[wave][prank] = lane;
-                    __builtin_amdgcn_wave_barrier(); // same wave: LDS operations complete in order, keep the compiler from reordering
-                    take = ((need >> lane) & 1ull) && rank < n_serve;
-                    if (take) n_ref = win_ref + s_pick[wave][rank];
-                    __builtin_amdgcn_wave_barrier();
-                    win_mask &= ~__ballot(give);
-                    taken += n_serve;
-                } else if (take) n_ref = nee.job_ref[cur + rank];
-                if (take) {
+                const uint32_t rank = mbcnt(need), avail = end - cur;
+                if (((need >> lane) & 1ull) && rank < avail) {
+                    n_ref = nee.job_ref[cur + rank];
                     const float2 j0 = nee.job_geo[3 * (size_t)n_ref], j1 = nee.job_geo[3 * (size_t)n_ref + 1], j2 = nee.job_geo[3 * (size_t)n_ref + 2];
-                    const float4 ja = make_float4(j0.x, j0.y, j1.x, j1.y), jb = make_float4(j2.x, j2.y, sc.anim_spheres ? nee.t0[n_ref % (uint32_t)nee.cap] : 0.0f, 0.0f);
-                    const f3 origin = sphere_center(h, jb.z); // TracedSDF origin at the packet time (extension; zero in the reference)
-                    n_scale = sdf_scale(h, jb.z);
-                    n_start = f3{ja.x, ja.y, ja.z} - origin;
-                    const f3 e = f3{ja.w, jb.x, jb.y} - origin;
+                    const float jt0 = sc.anim_spheres ? nee.t0[n_ref % (uint32_t)nee.cap] : 0.0f;
+                    const f3 origin = sphere_center(h, jt0); // TracedSDF origin at the packet time (extension; zero in the reference)
+                    n_scale = sdf_scale(h, jt0);
+                    n_start = f3{j0.x, j0.y, j1.x} - origin;
+                    const f3 e = f3{j1.y, j2.x, j2.y} - origin;
                     n_dir = e - n_start;
                     n_max = mag(n_dir);
                     n_dir = div_by_mag(n_dir, n_max);
                     n_has = true;
                 }
-                if (!SCAN) cur += min((uint32_t)__popcll(need), avail);
+                cur += min((uint32_t)__popcll(need), avail);
             }
         }
         if (!c_has && n_has) {
@@ -1098,9 +1059,6 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             if (exhausted) break;
             continue;
         }
-#ifdef RAYN_COUNT_TRIPS
-        if (COUNT && lane == 0) trips64 += 64;
-#endif
         if (c_has) { // TracedSDF::occluded, src/sdf.rs:25-57
             const f3 p = first ? start : muladd3(dir, t, start);
             const float dist = sdf_dist<COUNT>(h, p, evals, c_scale);
@@ -1119,10 +1077,6 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             if (res >= 0) { nee.vis[ref] = (uint8_t)res; c_has = false; }
         }
     }
-    if (SCAN && lane == 0 && taken) atomicAdd(&ctl->shadow_jobs, (unsigned long long)taken);
-#ifdef RAYN_COUNT_TRIPS
-    evals = trips64;
-#endif
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
@@ -1180,6 +1134,13 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
 // by termination key (bitonic network in registers + wave shuffles, below) and three lanes (r,g,b) accumulate them
 // sequentially.  Alpha/WorldNormal are depth-0 samples, ordered (object, sample).
 // ------------------------------------------------------------------------------------------------
+// where a tile's local pixel (x-major inside the tile, like the path pool) lives in the output film
+RD size_t film_pixel(const DTile& t, uint32_t lpix, uint32_t width) {
+    if (t.film_packed) return (size_t)t.film_base + lpix;
+    const uint32_t lx = lpix / t.eh, ly = lpix % t.eh;
+    return (size_t)(t.x0 + lx) + (size_t)(t.y0 + ly) * width;
+}
+
 // serial float sum of src[0], src[stride], .. (cnt terms) in index order (one lane = one channel); loads are issued eight at a time
 RD float serial_sum(const float* src, uint32_t stride, uint32_t cnt) {
     float a = 0.0f;
@@ -1283,8 +1244,7 @@ __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ s
     if (lpix >= tile.ew * tile.eh) return;
     const uint32_t spp = sc.spp, lane = threadIdx.x;
     const uint32_t P0 = tile.pool_base + lpix * spp;
-    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
-    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
+    const size_t fi = film_pixel(tile, lpix, sc.width);
     const float n = (float)spp;
     // ---- Color / Background in (depth, slot) order: key = depth:7 | slot:32 | background:1 | sample:12
     unsigned long long key[KPL];
@@ -1442,8 +1402,7 @@ __global__ void __launch_bounds__(256) k_resolve_big(const DScene* __restrict__ 
     if (lpix >= tile.ew * tile.eh) return;
     const uint32_t spp = sc.spp, tid = threadIdx.x;
     const uint32_t P0 = tile.pool_base + lpix * spp;
-    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
-    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
+    const size_t fi = film_pixel(tile, lpix, sc.width);
     const float n = (float)spp;
     // ---- Color / Background in (depth, slot) order
     unsigned long long key[KPL];
@@ -1589,8 +1548,7 @@ __global__ void __launch_bounds__(1024) k_resolve_huge(const DScene* __restrict_
     if (lpix >= tile.ew * tile.eh) return;
     const uint32_t spp = sc.spp, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t P0 = tile.pool_base + lpix * spp;
-    const uint32_t lx = lpix / tile.eh, ly = lpix % tile.eh;
-    const uint32_t fi = (tile.x0 + lx) + (tile.y0 + ly) * sc.width;
+    const size_t fi = film_pixel(tile, lpix, sc.width);
     const float n = (float)spp;
     // ---- Color / Background in (depth, slot) order
     unsigned long long key[KPL];
@@ -1706,24 +1664,26 @@ __global__ void __launch_bounds__(1024) k_resolve_huge(const DScene* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Multi-device film assembly (no reference counterpart; tiles are independent, src/film.rs:439-627): a device packs the
-// pixels of the tiles it rendered into one contiguous buffer (10 floats per pixel: Color 3 | Alpha 1 | Background 3 |
-// WorldNormal 3, tile after tile, pixel-major inside a tile like the path pool), the buffer crosses xGMI with ONE peer copy,
-// and device 0 scatters it into the caller's film.  pool_base of the DTile holds the tile's first pixel in the packed buffer.
+// Multi-device film assembly (no reference counterpart; tiles are independent, src/film.rs:439-627): a peer device resolves
+// the tiles it rendered straight into a PLANAR packed film (DTile::film_packed: Color 3N | Alpha N | Background 3N |
+// WorldNormal 3N floats for its N owned pixels, tile after tile, pixel-major inside a tile like the path pool), that buffer
+// crosses xGMI with ONE peer copy, and device 0 scatters it into the caller's film with this kernel.  film_base of the DTile
+// = the tile's first pixel in the packed planes.
 // ------------------------------------------------------------------------------------------------
-template <bool PACK>
-__global__ void __launch_bounds__(256) k_tile_pixels(const DTile* __restrict__ tiles, uint32_t width, float* __restrict__ color,
-                                                      float* __restrict__ alpha, float* __restrict__ background, float* __restrict__ normal,
-                                                      float* __restrict__ packed) {
+__global__ void __launch_bounds__(256) k_unpack_tiles(const DTile* __restrict__ tiles, uint32_t width, float* __restrict__ color,
+                                                       float* __restrict__ alpha, float* __restrict__ background, float* __restrict__ normal,
+                                                       const float* __restrict__ p_color, const float* __restrict__ p_alpha,
+                                                       const float* __restrict__ p_background, const float* __restrict__ p_normal) {
     const DTile t = tiles[blockIdx.x];
     const uint32_t npx = t.ew * t.eh;
     for (uint32_t i = threadIdx.x; i < npx * 10u; i += 256) {
         const uint32_t lpix = i / 10u, c = i - lpix * 10u;
         const uint32_t lx = lpix / t.eh, ly = lpix - lx * t.eh;
-        const size_t fi = (size_t)(t.x0 + lx) + (size_t)(t.y0 + ly) * width;
-        float* f = c < 3 ? color + 3 * fi + c : (c == 3 ? alpha + fi : (c < 7 ? background + 3 * fi + (c - 4) : normal + 3 * fi + (c - 7)));
-        float* q = packed + ((size_t)t.pool_base + lpix) * 10u + c;
-        if (PACK) *q = *f; else *f = *q;
+        const size_t fi = (size_t)(t.x0 + lx) + (size_t)(t.y0 + ly) * width, pi = (size_t)t.film_base + lpix;
+        if (c < 3) color[3 * fi + c] = p_color[3 * pi + c];
+        else if (c == 3) alpha[fi] = p_alpha[pi];
+        else if (c < 7) background[3 * fi + (c - 4)] = p_background[3 * pi + (c - 4)];
+        else normal[3 * fi + (c - 7)] = p_normal[3 * pi + (c - 7)];
     }
 }
 
@@ -1758,12 +1718,12 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
     if (i >= n) return;
     float r;
     switch (op) {
-    case 0: r = dm_expf(a[i]); break;
-    case 1: r = dm_sinf(a[i]); break;
-    case 2: r = dm_cosf(a[i]); break;
-    case 3: r = dm_tanf(a[i]); break;
-    case 4: r = dm_atan2f(a[i], b[i]); break;
-    case 5: r = dm_powf(a[i], b[i]); break;
+    case 0: r = dmf_expf(a[i]); break;
+    case 1: { float c_; dmf_sincosf(a[i], &r, &c_); }; break;
+    case 2: { float s_; dmf_sincosf(a[i], &s_, &r); }; break;
+    case 3: r = dmf_tanf(a[i]); break;
+    case 4: r = dmf_atan2f(a[i], b[i]); break;
+    case 5: r = dmf_powf(a[i], b[i]); break;
     case 6: r = div_nr(a[i], b[i]); break;
     case 7: r = a[i] / b[i]; break;
     case 8: r = sqrt_rn(a[i]); break;
@@ -1814,7 +1774,6 @@ static inline dim3 stride_grid(uint32_t max_items, uint32_t per_block, uint32_t 
     return dim3(std::max<uint32_t>(1u, std::min<uint32_t>(need, cap_blocks)));
 }
 constexpr uint32_t STREAM_BLOCKS = 256 * 8; // light streaming kernels: 8 blocks of 256 threads per CU
-constexpr uint32_t SETUP_BLOCKS = 256 * 12; // k_shade_setup: 6 resident blocks per CU, two rounds
 
 void launch_batch_setup(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t* pgrp_tile, uint32_t* tgb, uint32_t* tgc) {
     hipLaunchKernelGGL(k_batch_setup, dim3(n_tiles), dim3(256), 0, s, tiles, pgrp_tile, tgb, tgc);
@@ -1840,9 +1799,9 @@ void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t
 }
 void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
                         uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt,
-                        uint32_t* tile_cls_base) {
+                        uint32_t* tile_cls_base, uint32_t cap_groups) {
     hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, s, n_tiles, tile_total, tile_valid, tile_out_base, ogb, ogc, ctl, stage, nclass, pad, tile_cls_cnt,
-                       tile_cls_base);
+                       tile_cls_base, cap_groups);
 }
 void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
                         const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles,
@@ -1855,27 +1814,17 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
     hooks.before(0);
     const uint32_t shmem = ns > 4 ? VOL_MEMO_LIGHTS * 3 * 256 * 4 : 0; // ns > 4: the volume scatters (volume NEE samples exist)
-    if (tun.setup_stride) {
-        const dim3 sgrid = stride_grid(max_slots, 256, SETUP_BLOCKS);
-        if (count) hipLaunchKernelGGL((k_shade_setup<true, true>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
-        else hipLaunchKernelGGL((k_shade_setup<false, true>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
-    } else {
-        const dim3 sgrid = grid_for(max_slots, 256);
-        if (count) hipLaunchKernelGGL((k_shade_setup<true, false>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
-        else hipLaunchKernelGGL((k_shade_setup<false, false>), sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, tun.ablate, evals + 1);
-    }
+    const dim3 sgrid = grid_for(max_slots, 256);
+    if (count) hipLaunchKernelGGL(k_shade_setup<true>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, evals + 1);
+    else hipLaunchKernelGGL(k_shade_setup<false>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, evals + 1);
     hooks.after(0);
     if (has_sdf) {
         hooks.before(1);
-        const bool fast = single_sdf >= 0 && tun.fast_path, scan = fast && tun.shadow_scan;
-        if (!scan) hipLaunchKernelGGL(k_shadow_list, stride_grid(ns * max_slots, 256 * SCAN_ITEMS, STREAM_BLOCKS), dim3(256), 0, s, nee, ns, ctl);
+        hipLaunchKernelGGL(k_shadow_list, stride_grid(ns * max_slots, 256 * SCAN_ITEMS, STREAM_BLOCKS), dim3(256), 0, s, nee, ns, ctl);
         const dim3 grid = stride_grid(ns * max_slots, 256, tun.persistent_blocks);
-        if (scan) {
-            if (count) hipLaunchKernelGGL((k_shadow1<true, true>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
-            else hipLaunchKernelGGL((k_shadow1<false, true>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
-        } else if (fast) {
-            if (count) hipLaunchKernelGGL((k_shadow1<true, false>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
-            else hipLaunchKernelGGL((k_shadow1<false, false>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, ns, tun.prefetch_min_shadow, evals + 2);
+        if (single_sdf >= 0 && tun.fast_path) {
+            if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
+            else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
         } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
         else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
         hooks.after(1);
@@ -1889,11 +1838,11 @@ void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* al
                             const DCtl* ctl) {
     hipLaunchKernelGGL(k_compact_scatter, stride_grid(max_slots, 256, STREAM_BLOCKS), dim3(256), 0, s, bq, alive, grp_base, grp_tile, tile_out_base, ctl, qn, n_tiles, tile_total);
 }
-void launch_tile_pixels(hipStream_t s, bool pack, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha,
-                        float* background, float* normal, float* packed) {
+void launch_unpack_tiles(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha, float* background,
+                         float* normal, const float* packed, size_t packed_pixels) {
     if (!n_tiles) return;
-    if (pack) hipLaunchKernelGGL(k_tile_pixels<true>, dim3(n_tiles), dim3(256), 0, s, tiles, width, color, alpha, background, normal, packed);
-    else hipLaunchKernelGGL(k_tile_pixels<false>, dim3(n_tiles), dim3(256), 0, s, tiles, width, color, alpha, background, normal, packed);
+    const float *pc = packed, *pa = pc + 3 * packed_pixels, *pb = pa + packed_pixels, *pn = pb + 3 * packed_pixels;
+    hipLaunchKernelGGL(k_unpack_tiles, dim3(n_tiles), dim3(256), 0, s, tiles, width, color, alpha, background, normal, pc, pa, pb, pn);
 }
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
                     float* out_color, float* out_alpha, float* out_background, float* out_normal) {

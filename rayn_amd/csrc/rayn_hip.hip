@@ -3,8 +3,8 @@
 // Replaces the body of Film::render_frame_into (src/film.rs:382-628): builds the reference's tile
 // list, groups tiles into batches that fit the path pool, and for every batch runs
 //   ray-gen -> { extend -> bin (scan+scatter) -> shade -> repack (scan+scatter) } per depth -> resolve
-// on one HIP stream.  The only host<->device traffic inside a frame is two 8-byte queue-size
-// readbacks per depth (they size the next launches).
+// on the worker's HIP stream.  Queue sizes stay on the device (DCtl): a frame share is enqueued without host<->device round
+// trips (configurations deeper than 8 bounces peek at the queue size every 4th depth) and the host waits once, at the end.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -85,12 +85,13 @@ struct rayn_ctx {
     // single-device ctx (own streams, workers, arenas) on its device.  A render deals the share's tiles to the entries, each
     // renders its list (only_tiles), packs its pixels and sends them to device 0 with one peer copy (render_multi).
     std::vector<rayn_ctx*> peers;
-    struct PeerBuf { float* tables = nullptr; size_t tables_cap = 0; float* film = nullptr; size_t film_cap = 0; float* packed = nullptr; size_t packed_cap = 0;
-                     DTile* d_tiles = nullptr; size_t tiles_cap = 0; };
+    struct PeerBuf { float* tables = nullptr; size_t tables_cap = 0; float* packed = nullptr; size_t packed_cap = 0; };
     std::vector<PeerBuf> peer_bufs;                       // on the peer's device
     float* gather_buf = nullptr; size_t gather_cap = 0;   // on device 0: the packed pixels of all peers
     DTile* gather_tiles = nullptr; size_t gather_tiles_cap = 0;
     const std::vector<uint32_t>* only_tiles = nullptr;    // explicit (sorted) tile list of one sub-render
+    bool packed_film = false;        // sub-render of a peer: the out_* pointers are the planes of a packed film of the owned tiles (DTile::film_packed)
+    int budget_share = 1;            // entries of a multi-device context that share this ctx's GPU: the HBM budget is split between them
     int trace_tile = -1;             // diagnostics: dump the packet order of this tile (rayn_hip_set_trace_tile)
     std::vector<uint32_t> trace;     // records of 6 u32: depth, object, tile x, tile y, sample, valid
     int fma_policy = 0; // 0: mul_add unfused (reference default build), 1: fused
@@ -321,7 +322,8 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     const size_t JOBCAP = (size_t)NS * BCAP;
     size_t total_tiles = 0;
     for (auto& b : batches) total_tiles += b.size();
-    if (JOBCAP >= ((size_t)1 << 32) || BCAP >= ((size_t)1 << 31)) return wfail(w, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
+    // 32-bit [sample][slot] ids: k_shadow_list's grid-stride counter advances in steps of up to 2^25 ids and must not wrap
+    if (JOBCAP > ((size_t)1 << 32) - ((size_t)1 << 26) || BCAP >= ((size_t)1 << 31)) return wfail(w, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
     size_t need = 0;
     auto acc = [&](size_t n, size_t sz) { need += (n * sz + 255) & ~(size_t)255; };
     for (int i = 0; i < 5; i++) acc(CAP, 16);
@@ -407,7 +409,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
             {
                 Timed t(w, prof, PC_BIN);
                 K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0, hs.n_hitables, 4, tile_cls_cnt, tile_cls_base);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0, hs.n_hitables, 4, tile_cls_cnt, tile_cls_base, (uint32_t)(BCAP / 64));
                 K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, max_entries, bq, nt, tile_cls_cnt, tile_total, tile_cls_base, d_ctl);
             }
             if (ctx->trace_tile >= 0) { // diagnostics only (synchronises): packet order of one tile, in HitStore::process_hits order
@@ -452,7 +454,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
             {
                 Timed t(w, prof, PC_COMPACT);
                 K.scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid, tile_cls_cnt);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_ctl, 1, 1, 1, tile_cls_cnt, tile_cls_base);
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_ctl, 1, 1, 1, tile_cls_cnt, tile_cls_base, (uint32_t)(QCAP / 64));
                 K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, max_slots, qnext, nt, tile_total, d_ctl);
             }
             std::swap(qcur, qnext);
@@ -465,6 +467,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     WCHK(hipGetLastError());
     {
         const DCtl& c = *w->h_ctl;
+        if (c.overflow) return wfail(w, RAYN_ERR_HIP, c.overflow & 1u ? "internal: binned queue overflow" : "internal: ray queue overflow");
         w->stats.segments = c.segments; w->stats.shaded_slots = c.shaded_slots; w->stats.shadow_jobs = c.shadow_jobs;
         // algorithmic HBM bytes of the queue stages: bin = hist 1 B/entry + scatter q 4 + ent_obj 1 per entry, bq 4 per slot,
         // ~85 B of scan bookkeeping per group; repack = bq 4 + alive 1 per slot, q' 4 per survivor slot, ~9 B per group
@@ -494,7 +497,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     std::vector<TileRect> tiles = build_tiles(p->width, p->height, p->tile_w, p->tile_h);
     if (!ctx->tile_subset.empty() && ctx->tile_subset.back() >= tiles.size()) return fail(ctx, RAYN_ERR_INVALID_ARG, "tile subset index beyond the frame's tile count");
     std::vector<BatchTile> owned;
-    size_t owned_paths = 0;
+    size_t owned_paths = 0, packed_px = 0;
     for (uint32_t k = 0; k < tiles.size(); k++) {
         if (ctx->only_tiles) { if (!std::binary_search(ctx->only_tiles->begin(), ctx->only_tiles->end(), k)) continue; }
         else if (!ctx->tile_subset.empty()) { if (!std::binary_search(ctx->tile_subset.begin(), ctx->tile_subset.end(), k)) continue; }
@@ -503,7 +506,8 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         uint32_t ew = t.x1 - t.x0, eh = t.y1 - t.y0;
         if (!ew || !eh) continue;
         BatchTile bt; bt.tile_index = k;
-        bt.d = DTile{t.x0, t.y0, ew, eh, 0u, (uint32_t)((size_t)ew * eh * spp), {0, 0}};
+        bt.d = DTile{t.x0, t.y0, ew, eh, 0u, (uint32_t)((size_t)ew * eh * spp), ctx->packed_film ? (uint32_t)packed_px : 0u, ctx->packed_film ? 1u : 0u};
+        packed_px += (size_t)ew * eh;
         owned.push_back(bt);
         owned_paths += bt.d.n_paths;
     }
@@ -541,7 +545,9 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         for (const Worker& w : ctx->workers) free_b += w.arena.cap;
         const size_t per_path = 118 + 81 + 33 * (size_t)F.NS + 8 * ((size_t)F.NS - 3); // pool + queues | NEE records: fixed part, per light sample (pdf, vis, job ref, 24-B segment), per volume sample (vtr, aux)
-        const size_t budget_paths = (size_t)(0.6 * (double)free_b) / per_path;
+        // entries of a multi-device context that share one GPU (repeated device ids) size their arenas concurrently from the same
+        // free figure: each takes its share of the budget
+        const size_t budget_paths = (size_t)(0.6 * (double)free_b / (double)std::max(ctx->budget_share, 1)) / per_path;
         const int max_w = std::min(std::min(ctx->n_workers, MAX_WORKERS), (int)std::min<size_t>(owned.size(), MAX_WORKERS));
         for (int c = std::max(max_w, 1); c >= 1; c--) {
             // 32-bit [sample][slot] refs: NS * (binned slots of a batch) must stay below 2^32 (5 % slack for bin padding and tile tails)
@@ -602,8 +608,9 @@ template <typename T> int ensure(rayn_ctx* ctx, T** ptr, size_t* cap, size_t nee
 //     to entry (j + j / N) % N - the same rotating deal the ABI uses between ranks (whole tiles; their cost is very uneven);
 //  2. the sample tables / scramble / filter table are copied to every peer (<= tens of MB), scene descriptors are host data;
 //  3. one host thread per entry drives that entry's own wavefront renderer on its device;
-//  4. every peer packs the pixels of its tiles (10 floats each) and sends them to device 0 with ONE hipMemcpyPeerAsync over
-//     xGMI; device 0 scatters them into the caller's film.  No other data crosses devices.
+//  4. every peer resolves its tiles straight into a packed planar film of its owned pixels (10 floats per pixel; no
+//     full-resolution film exists on a peer) and sends it to device 0 with ONE hipMemcpyPeerAsync over xGMI; device 0 scatters
+//     the blocks into the caller's film.  No other data crosses devices.
 int render_multi(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, const float* d_s2, const float* d_scr, const float* d_fis,
                  float* d_color, float* d_alpha, float* d_bg, float* d_normal, hipStream_t stream) {
     int rc = validate(ctx, p);
@@ -637,7 +644,7 @@ int render_multi(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, c
     for (size_t e = 1; e < N; e++) {
         for (uint32_t k : lists[e]) {
             const TileRect& t = tiles[k];
-            packs[e].push_back(DTile{t.x0, t.y0, t.x1 - t.x0, t.y1 - t.y0, (uint32_t)pack_px[e], 0u, {0, 0}});
+            packs[e].push_back(DTile{t.x0, t.y0, t.x1 - t.x0, t.y1 - t.y0, 0u, 0u, (uint32_t)pack_px[e], 1u});
             pack_px[e] += (size_t)(t.x1 - t.x0) * (t.y1 - t.y0);
         }
         gather_off[e] = gather_px; gather_px += pack_px[e]; gather_nt += packs[e].size();
@@ -661,27 +668,25 @@ int render_multi(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, c
             return;
         }
         rayn_ctx::PeerBuf& B = ctx->peer_bufs[e - 1];
+        const size_t npk = std::max<size_t>(pack_px[e], 1);
         int r = ensure(c, &B.tables, &B.tables_cap, n_tab);
-        if (!r) r = ensure(c, &B.film, &B.film_cap, npx * RAYN_FILM_FLOATS_PER_PIXEL);
-        if (!r) r = ensure(c, &B.packed, &B.packed_cap, std::max<size_t>(pack_px[e], 1) * 10);
-        if (!r) r = ensure(c, &B.d_tiles, &B.tiles_cap, std::max<size_t>(packs[e].size(), 1));
+        if (!r) r = ensure(c, &B.packed, &B.packed_cap, npk * RAYN_FILM_FLOATS_PER_PIXEL);
         if (r) { c->only_tiles = nullptr; return bail(r, c->err); }
         float *t1 = B.tables, *t2 = t1 + n1, *tscr = t2 + n2, *tfis = tscr + npx;
-        float *fc = B.film, *fa = fc + 3 * npx, *fb = fa + npx, *fn = fb + 3 * npx;
+        // the peer's film IS the packed buffer: four planes over its owned pixels (the resolve writes them through DTile::film_base)
+        float *fc = B.packed, *fa = fc + 3 * pack_px[e], *fb = fa + pack_px[e], *fn = fb + 3 * pack_px[e];
         hipError_t he = hipMemcpyPeerAsync(t1, c->device, d_s1, ctx->device, n1 * 4, c->stream);
         if (he == hipSuccess) he = hipMemcpyPeerAsync(t2, c->device, d_s2, ctx->device, n2 * 4, c->stream);
         if (he == hipSuccess) he = hipMemcpyPeerAsync(tscr, c->device, d_scr, ctx->device, npx * 4, c->stream);
         if (he == hipSuccess) he = hipMemcpyPeerAsync(tfis, c->device, d_fis, ctx->device, RAYN_FIS_TABLE_SIZE * 4, c->stream);
         if (he != hipSuccess) { c->only_tiles = nullptr; return bail(RAYN_ERR_HIP, std::string("table broadcast: ") + hipGetErrorString(he)); }
+        c->packed_film = true;
         r = render_device(c, p, t1, t2, tscr, tfis, fc, fa, fb, fn, c->stream);
+        c->packed_film = false;
         c->only_tiles = nullptr;
         if (r) return bail(r, c->err);
-        if (!packs[e].empty()) {
-            he = hipMemcpyAsync(B.d_tiles, packs[e].data(), packs[e].size() * sizeof(DTile), hipMemcpyHostToDevice, c->stream);
-            if (he == hipSuccess) {
-                rayn_p0::launch_tile_pixels(c->stream, true, B.d_tiles, (uint32_t)packs[e].size(), p->width, fc, fa, fb, fn, B.packed);
-                he = hipMemcpyPeerAsync(ctx->gather_buf + gather_off[e] * 10, ctx->device, B.packed, c->device, pack_px[e] * 40, c->stream); // the one gather copy
-            }
+        if (pack_px[e]) {
+            he = hipMemcpyPeerAsync(ctx->gather_buf + gather_off[e] * 10, ctx->device, B.packed, c->device, pack_px[e] * 40, c->stream); // the one gather copy
             if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
             if (he != hipSuccess) return bail(RAYN_ERR_HIP, std::string("film gather: ") + hipGetErrorString(he));
         }
@@ -699,8 +704,8 @@ int render_multi(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, c
     for (size_t e = 1; e < N; e++) {
         if (packs[e].empty()) continue;
         HIPCHK(hipMemcpyAsync(ctx->gather_tiles + t_off, packs[e].data(), packs[e].size() * sizeof(DTile), hipMemcpyHostToDevice, stream));
-        rayn_p0::launch_tile_pixels(stream, false, ctx->gather_tiles + t_off, (uint32_t)packs[e].size(), p->width, d_color, d_alpha, d_bg, d_normal,
-                                    ctx->gather_buf + gather_off[e] * 10);
+        rayn_p0::launch_unpack_tiles(stream, ctx->gather_tiles + t_off, (uint32_t)packs[e].size(), p->width, d_color, d_alpha, d_bg, d_normal,
+                                     ctx->gather_buf + gather_off[e] * 10, pack_px[e]);
         t_off += packs[e].size();
     }
     HIPCHK(hipEventRecord(ctx->ev_mb, stream));
@@ -766,10 +771,7 @@ int rayn_hip_create(int device, rayn_ctx** out) {
     if (const char* e = getenv("RAYN_HIP_REFILL_SHADOW")) ctx->tun.refill_min_shadow = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("RAYN_HIP_PREFETCH_EXTEND")) ctx->tun.prefetch_min_extend = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("RAYN_HIP_PREFETCH_SHADOW")) ctx->tun.prefetch_min_shadow = (uint32_t)std::max(1, atoi(e));
-    if (const char* e = getenv("RAYN_HIP_ABLATE")) ctx->tun.ablate = (uint32_t)atoi(e);
     if (const char* e = getenv("RAYN_HIP_FAST_PATH")) ctx->tun.fast_path = atoi(e) != 0;
-    if (const char* e = getenv("RAYN_HIP_SHADOW_SCAN")) ctx->tun.shadow_scan = atoi(e) != 0;
-    if (const char* e = getenv("RAYN_HIP_SETUP_STRIDE")) ctx->tun.setup_stride = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_PERSISTENT_BLOCKS")) ctx->tun.persistent_blocks = (uint32_t)std::max(1, atoi(e));
     *out = ctx;
     return RAYN_OK;
@@ -797,6 +799,11 @@ int rayn_hip_create_multi(const int* devices, int n_devices, rayn_ctx** out) {
         }
     }
     ctx->peer_bufs.resize(ctx->peers.size());
+    for (int i = 0; i < n_devices; i++) { // entries sharing a GPU split its HBM budget
+        int share = 0;
+        for (int j = 0; j < n_devices; j++) share += devices[j] == devices[i];
+        (i == 0 ? ctx : ctx->peers[i - 1])->budget_share = share;
+    }
     (void)hipSetDevice(devices[0]);
     *out = ctx;
     return RAYN_OK;
@@ -812,9 +819,7 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
         if (i < ctx->peer_bufs.size()) {
             rayn_ctx::PeerBuf& B = ctx->peer_bufs[i];
             if (B.tables) (void)hipFree(B.tables);
-            if (B.film) (void)hipFree(B.film);
             if (B.packed) (void)hipFree(B.packed);
-            if (B.d_tiles) (void)hipFree(B.d_tiles);
         }
         rayn_hip_destroy(c);
     }
@@ -1006,6 +1011,7 @@ int rayn_hip_set_tile_subset(rayn_ctx* ctx, const uint32_t* tiles, uint32_t n) {
 }
 int rayn_hip_set_trace_tile(rayn_ctx* ctx, int tile_index) {
     if (!ctx) return RAYN_ERR_INVALID_ARG;
+    if (!ctx->peers.empty()) return fail(ctx, RAYN_ERR_INVALID_ARG, "rayn_hip_set_trace_tile is not supported on a multi-device context");
     ctx->trace_tile = tile_index;
     return RAYN_OK;
 }
@@ -1016,6 +1022,10 @@ int64_t rayn_hip_get_trace(const rayn_ctx* ctx, uint32_t* out, uint64_t cap_reco
     return (int64_t)n;
 }
 int rayn_hip_fma_policy(void) { return 0; }
+#ifndef RAYN_BUILD_VARIANT
+#define RAYN_BUILD_VARIANT ""
+#endif
+const char* rayn_hip_build_variant(void) { return RAYN_BUILD_VARIANT; }
 int rayn_hip_set_fma_policy(rayn_ctx* ctx, int policy) {
     if (!ctx || (policy != 0 && policy != 1)) return RAYN_ERR_INVALID_ARG;
     ctx->fma_policy = policy;

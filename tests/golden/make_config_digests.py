@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Oracle digests of WHOLE 16x16 tiles at the real BASELINE configurations.
+"""Oracle digests of WHOLE 16x16 tiles at every BASELINE configuration, under both mul_add policies where it matters.
 
 Packet grouping is per tile (src/hitable.rs:94-134, src/film.rs:456-529), so a 16x16 tile at 1024 / 4096 spp is a
-different computation from the 4x4-tile cases of FILM_CASES.  This script runs the CPU oracle on >= 8 spread tiles of
+different computation from the 4x4-tile cases of FILM_CASES.  This script runs the CPU oracle on
 
-    c3: 1920x1080, 1024 spp,  8 bounces, MandelBox + homogeneous volume   (the bench default)
-    c4: 3840x2160, 1024 spp, 12 bounces, MandelBox
-    c5: 7680x4320, 4096 spp, 16 bounces, MandelBox, moving camera + moving fractal (time-sampled motion blur)
+    c1:  256x256,     16 spp,  4 bounces, sphere SDF (BASELINE configs[0]) - ALL 256 tiles = the whole frame
+    c2: 1920x1080,   256 spp,  8 bounces, MandelBox                        - >= 8 spread tiles
+    c3: 1920x1080,  1024 spp,  8 bounces, MandelBox + homogeneous volume   (the bench default)
+    c4: 3840x2160,  1024 spp, 12 bounces, MandelBox
+    c5: 7680x4320,  4096 spp, 16 bounces, MandelBox, moving camera + moving fractal (time-sampled motion blur)
+    c1_fma, c3_fma: the same tiles as c1 / c3 with FUSED mul_add (librayn_oracle_fma.so = rayn built with +fma)
 
 at FULL resolution and tile size, and writes per tile: the path / segment / packet / SDF-evaluation counts and one
 SHA-256 per film channel over the tile's float32 pixels (film row order, NaNs canonicalised to 0x7FC00000).
@@ -16,9 +19,12 @@ Tile choice is deterministic: a 4-spp probe of ~200 spread tiles ranks them by s
 most and the least expensive tile (fractal-heavy / sky), the last tile of a column (half height at 1080 rows), the
 first tile, and evenly spaced quantiles of the ranking of the tiles that see more than sky.
 
-    python tests/golden/make_config_digests.py [c3 c4 c5] [--tiles 12] [--jobs N]      (writes config_digests.json)
+    python tests/golden/make_config_digests.py [c1 c2 c3 c4 c5 c1_fma c3_fma] [--tiles 12] [--jobs N]      (writes config_digests.json)
 
-About 15 core-minutes for c3, 5 for c4, 40 for c5 (one tile runs serially on one thread, like the reference).
+About 15 core-minutes for c3, 5 for c4, 40 for c5, seconds for c1 (one tile runs serially on one thread, like the reference).
+Every entry is stamped with `oracle_hash` = sha256 of the sources that define the oracle's arithmetic (oracle/rayn_oracle.cpp,
+include/rayn_detmath.h, include/rayn_hip.h): tests/test_config_digests.py warns when the stamp no longer matches the tree and
+re-derives a cheap part of every entry on the CPU, so a fixture that predates an oracle change cannot go unnoticed.
 """
 import argparse
 import hashlib
@@ -37,20 +43,40 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CONFIGS = {
     # name: (scene, W, H, samples (= spp / 4), bounces)
+    "c1": ("s0", 256, 256, 4, 4),
+    "c2": ("s1", 1920, 1080, 64, 8),
     "c3": ("s2", 1920, 1080, 256, 8),
     "c4": ("s1", 3840, 2160, 256, 12),
     "c5": ("s3", 7680, 4320, 1024, 16),
 }
+# fused-policy entries: (base config whose tile list is reused)
+FMA_CONFIGS = {"c1_fma": "c1", "c3_fma": "c3"}
 CHANNELS = ("color", "alpha", "background", "normal")
+
+
+def oracle_hash():
+    """sha256 over the sources that define the oracle's arithmetic."""
+    h = hashlib.sha256()
+    for f in ("oracle/rayn_oracle.cpp", "include/rayn_detmath.h", "include/rayn_hip.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def base_config(name):
+    return FMA_CONFIGS.get(name, name)
+
+
+def is_fma(name):
+    return name in FMA_CONFIGS
 
 
 def world_and_params(name, samples=None):
     """The scene + frame parameters of a config (shared with the GPU test)."""
     from rayn_amd import params as P
     from rayn_amd import setup as S
-    scene, W, H, smp, bounces = CONFIGS[name]
+    scene, W, H, smp, bounces = CONFIGS[base_config(name)]
     # s3 = config 5: moving camera (reference-supported closure) + moving fractal (TracedSDF transform_seq extension)
-    cam, world = {"s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3}[scene]((W, H))
+    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3}[scene]((W, H))
     p = P.frame_params(W, H, smp if samples is None else samples, bounces)
     return world.to_desc(cam), p
 
@@ -75,6 +101,8 @@ def tile_digests(film, p, k):
 
 def choose_tiles(name, n_pick, jobs, O):
     wd, p = world_and_params(name, samples=1)
+    if name == "c1":  # the whole frame
+        return list(range((p.width // p.tile_w) * (p.height // p.tile_h)))
     tabs = O.build_tables(4, p.max_bounces, p.volume_marches, p.frame, p.width, p.height)
     nx = (p.width + p.width % p.tile_w) // p.tile_w
     ny = (p.height + p.height % p.tile_h) // p.tile_h
@@ -102,7 +130,7 @@ def choose_tiles(name, n_pick, jobs, O):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("configs", nargs="*", default=["c3", "c4", "c5"])
+    ap.add_argument("configs", nargs="*", default=["c1", "c2", "c3", "c4", "c5", "c1_fma", "c3_fma"])
     ap.add_argument("--tiles", type=int, default=12)
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--out", default=os.path.join(HERE, "config_digests.json"))
@@ -112,22 +140,27 @@ def main():
     result = json.load(open(args.out)) if os.path.exists(args.out) else {}
     for name in args.configs:
         t0 = time.time()
-        tiles = choose_tiles(name, args.tiles, args.jobs, O)
+        fma = is_fma(name)
+        # a fused entry re-renders the tile list of its base config (same tiles under both policies)
+        tiles = [t["tile"] for t in result[base_config(name)]["tiles"]] if fma else choose_tiles(name, args.tiles, args.jobs, O)
         wd, p = world_and_params(name)
-        tabs = O.build_tables(4 * p.samples, p.max_bounces, p.volume_marches, p.frame, p.width, p.height)
+        tabs = O.build_tables(4 * p.samples, p.max_bounces, p.volume_marches, p.frame, p.width, p.height, fma=fma)
 
         def run(k):
-            film, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[k])
+            film, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[k], fma=fma)
             x0, y0, x1, y1 = tile_rect(p, k)
             return {"tile": k, "rect": [x0, y0, x1, y1], "paths": ctr.paths, "segments": ctr.segments, "packets": ctr.packets,
                     "dist_evals": ctr.dist_evals, "alpha_mean": float(film["alpha"][y0:y1, x0:x1].mean()), "sha256": tile_digests(film, p, k)}
 
         with ThreadPoolExecutor(min(args.jobs, 4 if name == "c5" else args.jobs)) as ex:  # c5: 1.3 GB of film per oracle call
             recs = list(ex.map(run, tiles))
-        scene, W, H, smp, bounces = CONFIGS[name]
+        scene, W, H, smp, bounces = CONFIGS[base_config(name)]
         result[name] = {"scene": scene, "width": W, "height": H, "samples": smp, "spp": 4 * smp, "max_bounces": bounces,
-                        "volume_marches": p.volume_marches, "frame": p.frame, "tile": [p.tile_w, p.tile_h], "tiles": recs,
-                        "oracle": "oracle/rayn_oracle.cpp, unfused mul_add (librayn_oracle.so)", "seconds": round(time.time() - t0, 1)}
+                        "volume_marches": p.volume_marches, "frame": p.frame, "tile": [p.tile_w, p.tile_h], "fma_policy": int(fma), "tiles": recs,
+                        "oracle": "oracle/rayn_oracle.cpp, " + ("FUSED mul_add (librayn_oracle_fma.so)" if fma else "unfused mul_add (librayn_oracle.so)"),
+                        "oracle_hash": oracle_hash(), "seconds": round(time.time() - t0, 1)}
+        if base_config(name) == "c1":  # every tile of the frame is listed: whole-frame counts
+            result[name]["frame_counts"] = {k: sum(r[k] for r in recs) for k in ("paths", "segments", "packets", "dist_evals")}
         json.dump(result, open(args.out, "w"), indent=1)
         print(name, "done in", round(time.time() - t0, 1), "s:", [(r["tile"], r["segments"]) for r in recs], flush=True)
 

@@ -85,3 +85,25 @@ def test_traced_sdf_transform_maps_to_the_hitable_fields():
     world.hitables[1].transform_seq = R.vec3(0.5, 0.25, -1.0)
     sdf = [h for h in world.to_desc(cam).hitables[:8] if h.kind == R._abi.HITABLE_TRACED_SDF][0]
     assert sdf.animated == 0 and (sdf.center.x, sdf.center.y, sdf.center.z) == (0.5, 0.25, -1.0)
+
+
+def test_product_source_carries_no_experiment_switches():
+    """The product kernels hold exactly one code path per policy: no wrong-by-design ablation builds, no rejected layouts of the
+    fold block, no opt-in kernels (VERDICT r2 weak #7).  Measured variants live in git history (tools/variants/README.md)."""
+    banned = re.compile(r"ABLATE|RAYN_FOLD_(BRANCHFREE|DENSE_BELOW|LIKELY|PLAIN_IF)|RAYN_PACKED_FOLD|RAYN_COUNT_(FOLDS|TRIPS)|"
+                        r"shadow_scan|setup_stride|SETUP_STRIDE|RAYN_FAST_DETMATH|\bSCAN\b")
+    csrc = os.path.join(ROOT, "rayn_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
+            for n, line in enumerate(open(os.path.join(csrc, f)), 1):
+                assert not banned.search(line), f"{f}:{n}: {line.strip()}"
+
+
+def test_variant_builds_are_never_loaded_silently(L, monkeypatch):
+    assert _lib.build_variant() == ""  # the in-tree library is the product build
+    monkeypatch.setenv("RAYN_HIP_LIB", "/nonexistent/librayn_hip_exp.so")
+    monkeypatch.delenv("RAYN_HIP_ALLOW_VARIANT", raising=False)
+    with pytest.raises(_lib.RaynHipError, match="RAYN_HIP_ALLOW_VARIANT"):
+        _lib._lib_path()
+    monkeypatch.setenv("RAYN_HIP_ALLOW_VARIANT", "1")
+    assert _lib._lib_path() == "/nonexistent/librayn_hip_exp.so"

@@ -34,3 +34,25 @@ def test_bench_two_ranks_one_gpu(ranks):
     assert out["n_gpus"] == ranks and out["steps"] == 1 and out["scaling"] == "strong"
     assert out["film_check"] is True
     assert out["value"] > 0 and out["config"]["paths_per_step"] == 256 * 256 * 16
+    # the all-reduced segment count of the partitioned frame == the count of the whole frame (c1 is deterministic)
+    assert out["segments_per_step"] == json.load(open(os.path.join(ROOT, "tests", "golden", "config_digests.json")))["c1"]["frame_counts"]["segments"]
+
+
+@pytest.mark.gpu
+def test_bench_rccl_code_path_world1():
+    """The process-group code path of the N>1 launch on the box's REAL RCCL: `torch.distributed.run --nproc-per-node=1 bench.py
+    --backend nccl --force-dist` initialises ProcessGroupNCCL with device_id, runs the barriers, the all-reduces (max time, summed
+    segment count) and FilmGather's pack -> dist.gather -> scatter (rank 0's own block included), then compares the gathered film
+    with a plain single-context render bit for bit.  What a one-GPU box cannot exercise is only the xGMI hop itself."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--workload", "c1", "--backend", "nccl", "--force-dist", "--check-film", "--cpu-seconds", "0", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["film_check"] is True
+    assert "RCCL gather" in out["config"]["parallelism"] and "TEST MODE" not in out["config"]["parallelism"]
+    assert out["segments_per_step"] > out["config"]["paths_per_step"]  # summed over ranks by all-reduce: every path has >= 1 segment

@@ -69,3 +69,35 @@ def test_ownership_is_a_partition():
         if (w, h) == (1920, 1080):
             sizes = [len(x) for x in parts]
             assert (max(sizes) - min(sizes)) / max(sizes) < 0.04  # the half-height last tile row lands on 2 of 8 ranks
+
+
+def _force_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rayn_amd.distributed import FilmGather, owned_pixels
+    W, H = 50, 37
+    rng = np.random.default_rng(7)  # same film on every rank: each contributes ITS pixels of it
+    full = {"color": rng.random((W * H, 3), np.float32), "alpha": rng.random(W * H, np.float32),
+            "background": rng.random((W * H, 3), np.float32), "normal": rng.random((W * H, 3), np.float32)}
+    mine = owned_pixels(W, H, 16, 16, rank, world)
+    film = {k: torch.zeros_like(torch.from_numpy(v)) for k, v in full.items()}
+    for k, v in full.items():
+        film[k][mine] = torch.from_numpy(v)[mine]
+    g = FilmGather(W, H, (16, 16), rank, world, "cpu", force=True)
+    if rank == 0:  # force: rank 0's own block travels through the collective too - wipe it to prove it comes back
+        keep = {k: v.clone() for k, v in film.items()}
+    out = g.gather(film)
+    if rank == 0:
+        covered = np.concatenate([owned_pixels(W, H, 16, 16, r, world) for r in range(world)])
+        for k, v in full.items():
+            assert np.array_equal(out[k].numpy()[covered], v[covered]), k
+            assert np.array_equal(out[k].numpy()[mine], keep[k].numpy()[mine])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_forced_gather_runs_the_collective_even_at_world_1(world):
+    """FilmGather(force=True) - the mode tests/test_bench_multirank.py uses to run the RCCL path on a one-GPU box."""
+    mp.spawn(_force_worker, args=(world, _free_port()), nprocs=world, join=True)

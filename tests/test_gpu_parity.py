@@ -20,7 +20,8 @@ def _rand(n, lo, hi, seed):
 @pytest.mark.parametrize("op,lo,hi", [(0, -30, 5), (1, -8, 8), (2, -8, 8), (3, -1.5, 1.5), (4, -6, 6), (5, 0, 1), (0, -110, 95), (1, -2e4, 2e4), (5, 0, 40)])
 def test_detmath_bit_exact(gpu_ctx, oracle, op, lo, hi):
     """The kernels' elementary functions against the oracle's evaluation of include/rayn_detmath.h: same bits on 2 M arguments per
-    case, incl. huge / tiny results and special values.  (The same test validates a -DRAYN_FAST_DETMATH build, RAYN_HIP_LIB.)"""
+    case, incl. huge / tiny results and special values.  The kernels evaluate them through include/rayn_detmath_fast.h (shorter
+    polynomials + rounding-safety test + fallback): this is the device-side proof that the shortcut returns rayn_detmath.h's bits."""
     import ctypes as C
     from rayn_amd._lib import lib
     n = 2_000_000
@@ -270,13 +271,13 @@ def test_two_workers_are_invisible(gpu_ctx, oracle):
 
 
 def test_tuning_variants_are_invisible(oracle, monkeypatch):
-    """The optional code paths behind the tuning switches (k_shadow1 scanning the visibility bytes itself, k_shade_setup as a
-    grid-stride loop) give the same film bit for bit."""
+    """The code paths behind the tuning switches (generic multi-SDF march kernels instead of the single-SDF fast path, other
+    refill / prefetch thresholds of the persistent waves, one worker) give the same film bit for bit."""
     import rayn_amd
     wd, p = case("s2", 48, 32, 2, 3)
     tabs = _tables(oracle, p)
     ref, ctr = oracle.render(wd, p, tabs)
-    for env in ({"RAYN_HIP_SHADOW_SCAN": "1"}, {"RAYN_HIP_SETUP_STRIDE": "1"}, {"RAYN_HIP_SHADOW_SCAN": "1", "RAYN_HIP_WORKERS": "1"}):
+    for env in ({"RAYN_HIP_FAST_PATH": "0"}, {"RAYN_HIP_PREFETCH_SHADOW": "8", "RAYN_HIP_PREFETCH_EXTEND": "60"}, {"RAYN_HIP_FAST_PATH": "0", "RAYN_HIP_REFILL_SHADOW": "1", "RAYN_HIP_WORKERS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = rayn_amd.Context(0)
