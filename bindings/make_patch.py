@@ -1,0 +1,666 @@
+"""Regenerates bindings/rayn.patch: the reference-side changes a rayn maintainer applies so that bindings/hip.rs +
+bindings/film_hip.rs compile inside rayn's `src/` (N1).
+
+The script copies the reference's `src/` + Cargo.toml into a scratch directory, applies the edits below as exact,
+assert-checked text replacements (so a changed reference fails loudly instead of producing a stale patch) and writes the
+unified diff.  It runs only in the build container (it reads /root/reference); the committed patch is what travels.
+usage: python bindings/make_patch.py [reference_root=/root/reference] [out=bindings/rayn.patch]"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(HERE, "rayn.patch")
+
+EDITS = {}
+
+
+def edit(path, old, new, count=1):
+    EDITS.setdefault(path, []).append((old, new, count))
+
+
+# ---- src/main.rs: the three new modules + an opt-in switch next to the CPU call -------------------------------------
+edit("src/main.rs", "mod film;\n", "mod film;\nmod film_hip;\n")
+edit("src/main.rs", "mod hitable;\n", "mod hip;\nmod hitable;\n")
+edit("src/main.rs", """    let (camera, world) = setup::setup();
+""", """    let (camera, world) = setup::setup();
+
+    // RAYN_HIP=0[,1,..]: render on those GPUs through librayn_hip.so (film_hip.rs); unset = the CPU path below.
+    let hip_ctx = std::env::var("RAYN_HIP").ok().map(|ids| {
+        let ids: Vec<i32> = ids.split(',').map(|s| s.trim().parse().expect("RAYN_HIP=<gpu>[,<gpu>..]")).collect();
+        hip::Context::new(&ids).expect("librayn_hip")
+    });
+""")
+edit("src/main.rs", """        film.render_frame_into(
+            &world,
+            camera,
+            &integrator,
+            &filter,
+            Extent2u::new(16, 16),
+            frame,
+            frame_start..frame_end,
+            crate::setup::SAMPLES,
+        );
+""", """        let on_gpu = match &hip_ctx {
+            Some(ctx) => match film.render_frame_into_hip(
+                ctx,
+                &world,
+                camera,
+                &integrator,
+                &filter,
+                Extent2u::new(16, 16),
+                frame,
+                frame_start..frame_end,
+                crate::setup::SAMPLES,
+            ) {
+                Ok(()) => true,
+                Err(e) => {
+                    println!("librayn_hip: {} - falling back to the CPU path", e);
+                    false
+                }
+            },
+            None => false,
+        };
+        if !on_gpu {
+            film.render_frame_into(
+                &world,
+                camera,
+                &integrator,
+                &filter,
+                Extent2u::new(16, 16),
+                frame,
+                frame_start..frame_end,
+                crate::setup::SAMPLES,
+            );
+        }
+""")
+
+# ---- src/animation.rs: a sequenced value can say whether it is `base + vel * t`; the nameable linear closure --------
+edit("src/animation.rs", """pub trait WSequenced<T>: Send + Sync {
+    fn sample_at(&self, t: f32x4) -> T;
+}
+""", """pub trait WSequenced<T>: Send + Sync {
+    fn sample_at(&self, t: f32x4) -> T;
+
+    /// Closed-set description for the HIP backend (hip.rs): `Some((base, vel))` when the value is `base + vel * t`
+    /// (`vel = 0` for a constant).  `None` - the default, e.g. an arbitrary closure - keeps the scene on the CPU path.
+    fn as_linear(&self) -> Option<(Vec3, Vec3)> {
+        None
+    }
+
+    /// `Some(c)` when the value is the constant scalar `c` (ThinLensCamera's aperture).
+    fn as_constant(&self) -> Option<f32> {
+        None
+    }
+}
+""")
+edit("src/animation.rs", "impl_wsequenced_for_sequenced!(f32 => f32x4, Vec2 => Wec2, Vec3 => Wec3);\n",
+     """impl_wsequenced_for_sequenced!(Vec2 => Wec2);
+
+// the `f32 => f32x4` and `Vec3 => Wec3` instances of the macro above, written out so that they can describe themselves
+impl WSequenced<f32x4> for f32 {
+    #[inline]
+    fn sample_at(&self, t: f32x4) -> f32x4 {
+        let ts = t.as_ref();
+        f32x4::from([
+            Sequenced::sample_at(self, ts[0]),
+            Sequenced::sample_at(self, ts[1]),
+            Sequenced::sample_at(self, ts[2]),
+            Sequenced::sample_at(self, ts[3]),
+        ])
+    }
+
+    fn as_constant(&self) -> Option<f32> {
+        Some(*self)
+    }
+}
+
+impl WSequenced<Wec3> for Vec3 {
+    #[inline]
+    fn sample_at(&self, t: f32x4) -> Wec3 {
+        let ts = t.as_ref();
+        Wec3::from([
+            Sequenced::sample_at(self, ts[0]),
+            Sequenced::sample_at(self, ts[1]),
+            Sequenced::sample_at(self, ts[2]),
+            Sequenced::sample_at(self, ts[3]),
+        ])
+    }
+
+    fn as_linear(&self) -> Option<(Vec3, Vec3)> {
+        Some((*self, Vec3::zero()))
+    }
+}
+
+/// The closure `move |t| base + vel * t` as a nameable type: same values as the closure (evaluated, like every
+/// `Fn(f32) -> Vec3`, at lane 0's time for all four lanes - see the impl below), but the HIP backend can read it.
+#[derive(Clone, Copy)]
+pub struct Linear {
+    pub base: Vec3,
+    pub vel: Vec3,
+}
+
+impl WSequenced<Wec3> for Linear {
+    #[inline]
+    fn sample_at(&self, t: f32x4) -> Wec3 {
+        let ts = t.as_ref();
+        let v = self.base + self.vel * ts[0];
+        [v, v, v, v].into()
+    }
+
+    fn as_linear(&self) -> Option<(Vec3, Vec3)> {
+        Some((self.base, self.vel))
+    }
+}
+""")
+
+# ---- the four traits gain `describe` with a default of None (= outside the closed set) ------------------------------
+edit("src/hitable.rs", """        half_pixel_size_at: &dyn Fn(f32x4) -> f32x4,
+    ) -> (MaterialHandle, WShadingPoint);
+}
+""", """        half_pixel_size_at: &dyn Fn(f32x4) -> f32x4,
+    ) -> (MaterialHandle, WShadingPoint);
+
+    /// POD description for the HIP backend (hip.rs); `None` = not in its closed set.
+    fn describe(&self) -> Option<crate::hip::RaynHitable> {
+        None
+    }
+}
+""")
+edit("src/material.rs", """        bump: &'bump Bump,
+    ) -> &'bump mut dyn BSDF;
+}
+""", """        bump: &'bump Bump,
+    ) -> &'bump mut dyn BSDF;
+
+    /// POD description for the HIP backend (hip.rs); `None` = not in its closed set.
+    fn describe(&self) -> Option<crate::hip::RaynMaterial> {
+        None
+    }
+}
+""")
+edit("src/light.rs", """        max_distance: f32x4,
+    ) -> (f32x4, f32x4);
+}
+""", """        max_distance: f32x4,
+    ) -> (f32x4, f32x4);
+
+    /// POD description for the HIP backend (hip.rs); `None` = not in its closed set.
+    fn describe(&self) -> Option<crate::hip::RaynLight> {
+        None
+    }
+}
+""")
+edit("src/camera.rs", """    fn half_pixel_size_at(&self, t: f32x4) -> f32x4;
+}
+""", """    fn half_pixel_size_at(&self, t: f32x4) -> f32x4;
+
+    /// POD description for the HIP backend (hip.rs); `None` = not in its closed set.
+    fn describe(&self) -> Option<crate::hip::RaynCamera> {
+        None
+    }
+}
+""")
+
+# ---- src/sphere.rs ---------------------------------------------------------------------------------------------------
+edit("src/sphere.rs", """        let t = f32x4::merge(take_t1, t1, t2);
+
+        f32x4::merge(t1_valid | t2_valid, t, miss)
+    }
+""", """        let t = f32x4::merge(take_t1, t1, t2);
+
+        f32x4::merge(t1_valid | t2_valid, t, miss)
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynHitable> {
+        let (center, vel) = self.transform_seq.as_linear()?;
+        let mut d = crate::hip::RaynHitable::default();
+        d.kind = crate::hip::RAYN_HITABLE_SPHERE;
+        d.material = self.material.0 as u32;
+        d.center = center.into();
+        d.radius = self.radius;
+        d.animated = (vel.x != 0.0 || vel.y != 0.0 || vel.z != 0.0) as u32;
+        d.center_vel = vel.into();
+        Some(d)
+    }
+""")
+
+# ---- src/sdf.rs: the SDFs keep their constructor arguments; TracedSDF<S> describes itself through S ------------------
+edit("src/sdf.rs", "const MAX_MARCHES: u32 = 256;\nconst MAX_VIS_MARCHES: u32 = 100;\n",
+     """pub(crate) const MAX_MARCHES: u32 = 256;
+pub(crate) const MAX_VIS_MARCHES: u32 = 100;
+
+/// What an SDF tells the HIP backend (hip.rs) about itself: fills the `sdf_*` fields of the descriptor and returns
+/// true, or returns false (the default) when it is outside the closed set.  `TracedSDF<S>` needs `S: DescribeSdf`;
+/// an SDF that should simply stay on the CPU path writes `impl DescribeSdf for MySdf {}`.
+pub trait DescribeSdf {
+    fn describe_sdf(&self, _into: &mut crate::hip::RaynHitable) -> bool {
+        false
+    }
+}
+""")
+edit("src/sdf.rs", "impl<S: SDF<f32x4, Wec3> + Send + Sync> Hitable for TracedSDF<S> {\n",
+     "impl<S: SDF<f32x4, Wec3> + DescribeSdf + Send + Sync> Hitable for TracedSDF<S> {\n")
+edit("src/sdf.rs", """            WShadingPoint::new(hit, point, half_pixel_size, normal),
+        )
+    }
+}
+""", """            WShadingPoint::new(hit, point, half_pixel_size, normal),
+        )
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynHitable> {
+        let mut d = crate::hip::RaynHitable::default();
+        d.kind = crate::hip::RAYN_HITABLE_TRACED_SDF;
+        d.material = self.material.0 as u32;
+        if self.sdf.describe_sdf(&mut d) {
+            Some(d)
+        } else {
+            None
+        }
+    }
+}
+""")
+edit("src/sdf.rs", """pub struct MandelBox {
+    iterations: usize,
+    scale: f32x4,
+""", """pub struct MandelBox {
+    iterations: usize,
+    scale_arg: f32,
+    scale: f32x4,
+""")
+edit("src/sdf.rs", """            sphere_fold,
+            scale: scale.into(),
+""", """            sphere_fold,
+            scale_arg: scale,
+            scale: scale.into(),
+""")
+edit("src/sdf.rs", """        let d = p.mag() / dr.abs();
+        d
+    }
+}
+""", """        let d = p.mag() / dr.abs();
+        d
+    }
+}
+
+impl DescribeSdf for MandelBox {
+    fn describe_sdf(&self, into: &mut crate::hip::RaynHitable) -> bool {
+        into.sdf_kind = crate::hip::RAYN_SDF_MANDELBOX;
+        into.iterations = self.iterations as u32;
+        into.box_side = self.box_fold.side_length;
+        into.min_radius = self.sphere_fold.min_radius;
+        into.fixed_radius = self.sphere_fold.fixed_radius;
+        into.scale = self.scale_arg;
+        true
+    }
+}
+""")
+edit("src/sdf.rs", """pub struct BoxFold {
+    l: Wec3,
+""", """pub struct BoxFold {
+    side_length: f32,
+    l: Wec3,
+""")
+edit("src/sdf.rs", """        BoxFold {
+            l,
+""", """        BoxFold {
+            side_length,
+            l,
+""")
+edit("src/sdf.rs", """pub struct SphereFold {
+    min_rad_sq: f32x4,
+""", """pub struct SphereFold {
+    min_radius: f32,
+    fixed_radius: f32,
+    min_rad_sq: f32x4,
+""")
+edit("src/sdf.rs", """        Self {
+            min_rad_sq,
+            fixed_rad_sq,
+        }
+    }
+
+    pub fn sphere_fold""", """        Self {
+            min_radius,
+            fixed_radius,
+            min_rad_sq,
+            fixed_rad_sq,
+        }
+    }
+
+    pub fn sphere_fold""")
+
+# ---- src/material.rs --------------------------------------------------------------------------------------------------
+edit("src/material.rs", """    pub fn get(&self, handle: MaterialHandle) -> &dyn Material {
+        self.0[handle.0].as_ref()
+    }
+}
+""", """    pub fn get(&self, handle: MaterialHandle) -> &dyn Material {
+        self.0[handle.0].as_ref()
+    }
+
+    pub fn len(&self) -> usize {
+        self.0.len()
+    }
+
+    pub fn iter(&self) -> impl Iterator<Item = &dyn Material> + '_ {
+        self.0.iter().map(|b| b.as_ref())
+    }
+}
+""")
+edit("src/material.rs", """pub trait WShadingParamGenerator<T> {
+    fn gen(&self, intersection: &WShadingPoint) -> T;
+}
+
+impl<T, I: Into<T> + Copy> WShadingParamGenerator<T> for I {
+    fn gen(&self, _intersection: &WShadingPoint) -> T {
+        (*self).into()
+    }
+}
+""", """pub trait WShadingParamGenerator<T> {
+    fn gen(&self, intersection: &WShadingPoint) -> T;
+
+    /// `Some(value)` when the parameter does not depend on the intersection (what the HIP backend can take).
+    fn constant(&self) -> Option<T> {
+        None
+    }
+}
+
+impl<T, I: Into<T> + Copy> WShadingParamGenerator<T> for I {
+    fn gen(&self, _intersection: &WShadingPoint) -> T {
+        (*self).into()
+    }
+
+    fn constant(&self) -> Option<T> {
+        Some((*self).into())
+    }
+}
+
+/// lane 0 of a splatted colour (every lane of a constant parameter holds the same value)
+fn lane0_rgb(c: WSrgb) -> crate::hip::RaynVec3 {
+    crate::hip::RaynVec3 {
+        x: crate::hip::lane0(c.x),
+        y: crate::hip::lane0(c.y),
+        z: crate::hip::lane0(c.z),
+    }
+}
+""")
+edit("src/material.rs", """        bump.alloc_with(|| LambertianBSDF {
+            albedo: self.albedo_gen.gen(intersection),
+        })
+    }
+}
+""", """        bump.alloc_with(|| LambertianBSDF {
+            albedo: self.albedo_gen.gen(intersection),
+        })
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynMaterial> {
+        let mut d = crate::hip::RaynMaterial::default();
+        d.kind = crate::hip::RAYN_MAT_LAMBERTIAN;
+        d.a = lane0_rgb(self.albedo_gen.constant()?);
+        Some(d)
+    }
+}
+""")
+edit("src/material.rs", """        bump.alloc_with(|| DielectricBSDF {
+            albedo: self.albedo_gen.gen(intersection),
+            roughness: self.roughness_gen.gen(intersection),
+        })
+    }
+}
+""", """        bump.alloc_with(|| DielectricBSDF {
+            albedo: self.albedo_gen.gen(intersection),
+            roughness: self.roughness_gen.gen(intersection),
+        })
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynMaterial> {
+        let mut d = crate::hip::RaynMaterial::default();
+        d.kind = crate::hip::RAYN_MAT_DIELECTRIC;
+        d.a = lane0_rgb(self.albedo_gen.constant()?);
+        // the REMAPPED roughness (Dielectric::new_remap above), i.e. the Phong exponent DielectricBSDF works with
+        d.exponent = crate::hip::lane0(self.roughness_gen.constant()?);
+        Some(d)
+    }
+}
+""")
+edit("src/material.rs", """        bump.alloc_with(|| SkyBSDF {
+            top: WSrgb::splat(self.top),
+            bottom: WSrgb::splat(self.bottom),
+        })
+    }
+}
+""", """        bump.alloc_with(|| SkyBSDF {
+            top: WSrgb::splat(self.top),
+            bottom: WSrgb::splat(self.bottom),
+        })
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynMaterial> {
+        let mut d = crate::hip::RaynMaterial::default();
+        d.kind = crate::hip::RAYN_MAT_SKY;
+        d.a = (*self.top).into();
+        d.b = (*self.bottom).into();
+        Some(d)
+    }
+}
+""")
+edit("src/material.rs", """            inner: LambertianBSDF {
+                albedo: WSrgb::new_splat(0.5, 0.5, 0.5),
+            },
+        })
+    }
+}
+""", """            inner: LambertianBSDF {
+                albedo: WSrgb::new_splat(0.5, 0.5, 0.5),
+            },
+        })
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynMaterial> {
+        let mut d = crate::hip::RaynMaterial::default();
+        d.kind = crate::hip::RAYN_MAT_EMISSIVE;
+        d.a = lane0_rgb(self.emission_gen.constant()?);
+        Some(d)
+    }
+}
+""")
+
+# ---- src/light.rs: SphereLight keeps its scalar constructor arguments -----------------------------------------------
+edit("src/light.rs", """pub struct SphereLight {
+    pos: Wec3,
+""", """pub struct SphereLight {
+    desc: crate::hip::RaynLight,
+    pos: Wec3,
+""")
+edit("src/light.rs", """        Self {
+            pos: Wec3::splat(pos),
+""", """        Self {
+            desc: crate::hip::RaynLight {
+                pos: pos.into(),
+                rad,
+                emission: (*emission).into(),
+                _pad: 0,
+            },
+            pos: Wec3::splat(pos),
+""")
+edit("src/light.rs", """impl Light for SphereLight {
+""", """impl Light for SphereLight {
+    fn describe(&self) -> Option<crate::hip::RaynLight> {
+        Some(self.desc)
+    }
+
+""")
+
+# ---- src/camera.rs: the cameras keep (resolution, vfov | vertical_size) ---------------------------------------------
+edit("src/camera.rs", """pub struct PinholeCamera<O, A, U> {
+    half_size: Wec2,
+""", """pub struct PinholeCamera<O, A, U> {
+    resolution: Vec2,
+    vfov: f32,
+    half_size: Wec2,
+""")
+edit("src/camera.rs", """        PinholeCamera {
+            half_size: Wec2::splat(Vec2::new(half_width, half_height)),
+""", """        PinholeCamera {
+            resolution,
+            vfov,
+            half_size: Wec2::splat(Vec2::new(half_width, half_height)),
+""")
+edit("src/camera.rs", """pub struct ThinLensCamera<A, O, LA, U, F> {
+    half_size: Wec2,
+""", """pub struct ThinLensCamera<A, O, LA, U, F> {
+    resolution: Vec2,
+    vfov: f32,
+    half_size: Wec2,
+""")
+edit("src/camera.rs", """        ThinLensCamera {
+            half_size: Wec2::splat(Vec2::new(half_width, half_height)),
+""", """        ThinLensCamera {
+            resolution,
+            vfov,
+            half_size: Wec2::splat(Vec2::new(half_width, half_height)),
+""")
+edit("src/camera.rs", """pub struct OrthographicCamera<O, A, U> {
+    half_size: Wec2,
+""", """pub struct OrthographicCamera<O, A, U> {
+    resolution: Vec2,
+    vertical_size: f32,
+    half_size: Wec2,
+""")
+edit("src/camera.rs", """        Self {
+            half_size: Wec2::splat(size / 2.0),
+""", """        Self {
+            resolution,
+            vertical_size,
+            half_size: Wec2::splat(size / 2.0),
+""")
+edit("src/camera.rs", """    fn half_pixel_size_at(&self, t: f32x4) -> f32x4 {
+        self.half_pixel_size * t
+    }
+}
+#[derive(Clone, Copy)]
+pub struct ThinLensCamera""", """    fn half_pixel_size_at(&self, t: f32x4) -> f32x4 {
+        self.half_pixel_size * t
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynCamera> {
+        let mut d = crate::hip::RaynCamera::default();
+        d.kind = crate::hip::RAYN_CAM_PINHOLE;
+        d.res_w = self.resolution.x;
+        d.res_h = self.resolution.y;
+        d.vfov_or_size = self.vfov;
+        d.set_origin(self.origin.as_linear()?);
+        d.set_at(self.at.as_linear()?);
+        d.set_up(self.up.as_linear()?);
+        Some(d)
+    }
+}
+#[derive(Clone, Copy)]
+pub struct ThinLensCamera""")
+edit("src/camera.rs", """    fn half_pixel_size_at(&self, t: f32x4) -> f32x4 {
+        self.half_pixel_size * t
+    }
+}
+
+#[derive(Clone, Copy)]
+pub struct OrthographicCamera""", """    fn half_pixel_size_at(&self, t: f32x4) -> f32x4 {
+        self.half_pixel_size * t
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynCamera> {
+        let mut d = crate::hip::RaynCamera::default();
+        d.kind = crate::hip::RAYN_CAM_THIN_LENS;
+        d.res_w = self.resolution.x;
+        d.res_h = self.resolution.y;
+        d.vfov_or_size = self.vfov;
+        d.aperture = self.aperture.as_constant()?;
+        d.set_origin(self.origin.as_linear()?);
+        d.set_at(self.at.as_linear()?);
+        d.set_up(self.up.as_linear()?);
+        d.set_focus(self.focus.as_linear()?);
+        Some(d)
+    }
+}
+
+#[derive(Clone, Copy)]
+pub struct OrthographicCamera""")
+edit("src/camera.rs", """    fn half_pixel_size_at(&self, _t: f32x4) -> f32x4 {
+        self.half_pixel_size
+    }
+}
+""", """    fn half_pixel_size_at(&self, _t: f32x4) -> f32x4 {
+        self.half_pixel_size
+    }
+
+    fn describe(&self) -> Option<crate::hip::RaynCamera> {
+        let mut d = crate::hip::RaynCamera::default();
+        d.kind = crate::hip::RAYN_CAM_ORTHOGRAPHIC;
+        d.res_w = self.resolution.x;
+        d.res_h = self.resolution.y;
+        d.vfov_or_size = self.vertical_size;
+        d.set_origin(self.origin.as_linear()?);
+        d.set_at(self.at.as_linear()?);
+        d.set_up(self.up.as_linear()?);
+        Some(d)
+    }
+}
+""")
+
+# ---- src/film.rs, src/filter.rs: what film_hip.rs (another module) has to reach -------------------------------------
+edit("src/film.rs", """    channels: Mutex<GenericArray<ChannelStorage, N>>,
+    progressive_epoch: usize,
+    this_epoch_tiles_finished: AtomicUsize,
+    res: Extent2u,
+}
+""", """    pub(crate) channels: Mutex<GenericArray<ChannelStorage, N>>,
+    pub(crate) progressive_epoch: usize,
+    this_epoch_tiles_finished: AtomicUsize,
+    pub(crate) res: Extent2u,
+}
+""")
+edit("src/filter.rs", """pub struct FilterImportanceSampler {
+    inverse_cdf: [f32; FILTER_TABLE_SIZE],
+}
+""", """pub struct FilterImportanceSampler {
+    pub(crate) inverse_cdf: [f32; FILTER_TABLE_SIZE],
+}
+""")
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="rayn_patch_")
+    try:
+        for side in ("a", "b"):
+            os.makedirs(os.path.join(tmp, side))
+            shutil.copytree(os.path.join(REF, "src"), os.path.join(tmp, side, "src"))
+        for path, edits in EDITS.items():
+            f = os.path.join(tmp, "b", path)
+            text = open(f).read()
+            for old, new, count in edits:
+                assert text.count(old) == count, f"{path}: expected {count} occurrence(s) of {old!r}, found {text.count(old)}"
+                text = text.replace(old, new)
+            open(f, "w").write(text)
+        r = subprocess.run(["diff", "-ruN", "a/src", "b/src"], cwd=tmp, capture_output=True, text=True)
+        assert r.returncode == 1, r.stderr
+        # drop diff's timestamps: the patch should not change from run to run
+        lines = []
+        for ln in r.stdout.splitlines(keepends=True):
+            if ln.startswith("diff -ruN "):
+                continue
+            if ln.startswith(("--- a/", "+++ b/")):
+                ln = ln.split("\t")[0] + "\n"
+            lines.append(ln)
+        open(OUT, "w").write("".join(lines))
+        print(f"wrote {OUT}: {len(lines)} lines, {len(EDITS)} files")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,6 @@
-//! rayn_hip.rs — `extern "C"` binding of librayn_hip.so for rayn (drop into `src/hip.rs`, add `mod hip;` to `src/main.rs`).
+//! rayn_hip.rs — `extern "C"` binding of librayn_hip.so for rayn.  Copy to `src/hip.rs`, copy film_hip.rs to `src/film_hip.rs`
+//! and apply bindings/rayn.patch (adds `mod hip; mod film_hip;`, the `describe()` methods of the scene types and three
+//! `pub(crate)`s); link with `cargo rustc -- -L <dir of librayn_hip.so>` or a two-line build.rs.
 //!
 //! Mirrors include/rayn_hip.h field for field.  UNTESTED AS RUST: no Rust toolchain exists in the build environment
 //!.  What IS tested (tests/test_bindings.py, every round): the `#[repr(C)]` field lists below — names, order
@@ -13,6 +15,20 @@ pub const RAYN_MAX_HITABLES: usize = 16;
 pub const RAYN_MAX_MATERIALS: usize = 16;
 pub const RAYN_MAX_LIGHTS: usize = 16;
 pub const RAYN_FIS_TABLE_SIZE: usize = 512; // FILTER_TABLE_SIZE, src/filter.rs:187
+
+// rayn_hitable_kind / rayn_sdf_kind / rayn_material_kind / rayn_camera_kind of include/rayn_hip.h
+pub const RAYN_HITABLE_SPHERE: u32 = 0;
+pub const RAYN_HITABLE_TRACED_SDF: u32 = 1;
+pub const RAYN_SDF_SPHERE: u32 = 0;
+pub const RAYN_SDF_MANDELBOX: u32 = 1;
+pub const RAYN_SDF_MANDELBULB: u32 = 2;
+pub const RAYN_MAT_LAMBERTIAN: u32 = 0;
+pub const RAYN_MAT_DIELECTRIC: u32 = 1;
+pub const RAYN_MAT_SKY: u32 = 2;
+pub const RAYN_MAT_EMISSIVE: u32 = 3;
+pub const RAYN_CAM_PINHOLE: u32 = 0;
+pub const RAYN_CAM_THIN_LENS: u32 = 1;
+pub const RAYN_CAM_ORTHOGRAPHIC: u32 = 2;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
@@ -192,4 +208,92 @@ pub fn check_layout() -> Result<(), String> {
         }
     }
     Ok(())
+}
+
+// ---- glue used by the `describe()` methods bindings/rayn.patch adds to rayn's scene types ---------------------------------
+
+impl From<crate::math::Vec3> for RaynVec3 {
+    fn from(v: crate::math::Vec3) -> Self {
+        RaynVec3 { x: v.x, y: v.y, z: v.z }
+    }
+}
+
+/// lane 0 of a wide value (`f32x4::as_ref` -> `[f32; 4]`, the idiom of src/animation.rs:39-41)
+pub fn lane0(v: crate::math::f32x4) -> f32 {
+    let lanes = v.as_ref();
+    lanes[0]
+}
+
+fn moves(vel: crate::math::Vec3) -> bool {
+    vel.x != 0.0 || vel.y != 0.0 || vel.z != 0.0
+}
+
+/// `(base, vel)` of `WSequenced::as_linear` into the descriptor: bit 0 origin, 1 at, 2 up, 3 focus of `animated`
+impl RaynCamera {
+    pub fn set_origin(&mut self, (base, vel): (crate::math::Vec3, crate::math::Vec3)) {
+        self.origin = base.into();
+        self.origin_vel = vel.into();
+        self.animated |= (moves(vel) as u32) << 0;
+    }
+    pub fn set_at(&mut self, (base, vel): (crate::math::Vec3, crate::math::Vec3)) {
+        self.at = base.into();
+        self.at_vel = vel.into();
+        self.animated |= (moves(vel) as u32) << 1;
+    }
+    pub fn set_up(&mut self, (base, vel): (crate::math::Vec3, crate::math::Vec3)) {
+        self.up = base.into();
+        self.up_vel = vel.into();
+        self.animated |= (moves(vel) as u32) << 2;
+    }
+    pub fn set_focus(&mut self, (base, vel): (crate::math::Vec3, crate::math::Vec3)) {
+        self.focus = base.into();
+        self.focus_vel = vel.into();
+        self.animated |= (moves(vel) as u32) << 3;
+    }
+}
+
+/// Owning handle of a `rayn_ctx` (one GPU, or several: `rayn_hip_create_multi`).  Every failing call returns the library's
+/// message (`rayn_hip_last_error`) as `Err(String)` - the hot path of the reference panics instead (src/film.rs:127,667).
+pub struct Context {
+    raw: *mut RaynCtx,
+}
+
+// the library serialises calls on one ctx itself (include/rayn_hip.h: "not re-entrant per ctx"); the handle is moved, not shared
+unsafe impl Send for Context {}
+
+impl Context {
+    pub fn new(devices: &[i32]) -> Result<Self, String> {
+        check_layout()?;
+        let mut raw: *mut RaynCtx = std::ptr::null_mut();
+        let rc = unsafe {
+            if devices.len() == 1 {
+                rayn_hip_create(devices[0], &mut raw)
+            } else {
+                rayn_hip_create_multi(devices.as_ptr(), devices.len() as i32, &mut raw)
+            }
+        };
+        if rc != 0 || raw.is_null() {
+            return Err(format!("rayn_hip_create{:?} failed with status {}", devices, rc));
+        }
+        Ok(Context { raw })
+    }
+
+    pub fn raw(&self) -> *mut RaynCtx {
+        self.raw
+    }
+
+    /// status -> Result, with the library's text
+    pub fn check(&self, rc: i32) -> Result<(), String> {
+        if rc == 0 {
+            return Ok(());
+        }
+        let msg = unsafe { std::ffi::CStr::from_ptr(rayn_hip_last_error(self.raw)) };
+        Err(format!("librayn_hip status {}: {}", rc, msg.to_string_lossy()))
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { rayn_hip_destroy(self.raw) }
+    }
 }

@@ -96,3 +96,130 @@ def test_extern_fns_are_exported_and_declared():
     shim = open(os.path.join(ROOT, "bindings", "film_hip.rs")).read()
     for f in set(re.findall(r"\b(rayn_hip_\w+)\(", shim)):
         assert f in fns, f
+
+
+# ---- the reference-side patch (bindings/rayn.patch) and the shim's use of rayn's items ------------------------------------
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+REFERENCE = "/root/reference"
+needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "src")) or shutil.which("git") is None,
+                                     reason="the reference checkout (build container only) and git are needed")
+
+# std / generic-array / rand items film_hip.rs calls; everything else it calls must be defined in rayn (patched) or hip.rs
+STD_METHODS = {"len", "iter", "iter_mut", "enumerate", "lock", "unwrap", "zip", "chunks_exact", "copy_from_slice", "as_ptr", "as_mut_ptr",
+               "ok_or_else", "gen", "from", "seed_from_u64", "new"}
+
+
+@pytest.fixture(scope="module")
+def patched_src(tmp_path_factory):
+    """reference src/ + bindings/rayn.patch (git apply) + hip.rs + film_hip.rs, as a maintainer would have it"""
+    d = tmp_path_factory.mktemp("rayn_patched")
+    shutil.copytree(os.path.join(REFERENCE, "src"), d / "src")
+    subprocess.run(["git", "init", "-q", "."], cwd=d, check=True)
+    patch = os.path.join(ROOT, "bindings", "rayn.patch")
+    r = subprocess.run(["git", "apply", "--check", "-p1", patch], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    subprocess.run(["git", "apply", "-p1", patch], cwd=d, check=True)
+    shutil.copy(os.path.join(ROOT, "bindings", "rayn_hip.rs"), d / "src" / "hip.rs")
+    shutil.copy(os.path.join(ROOT, "bindings", "film_hip.rs"), d / "src" / "film_hip.rs")
+    return d / "src"
+
+
+def strip_rust_comments(text):
+    return re.sub(r"//[^\n]*", "", text)
+
+
+@needs_reference
+def test_patch_applies_and_is_what_make_patch_generates(patched_src, tmp_path):
+    out = tmp_path / "regen.patch"
+    subprocess.run([sys.executable, os.path.join(ROOT, "bindings", "make_patch.py"), REFERENCE, str(out)], check=True, capture_output=True)
+    assert out.read_text() == open(os.path.join(ROOT, "bindings", "rayn.patch")).read(), "bindings/rayn.patch is stale: run bindings/make_patch.py"
+    main = (patched_src / "main.rs").read_text()
+    assert "mod hip;" in main and "mod film_hip;" in main and "render_frame_into_hip" in main
+
+
+@needs_reference
+def test_patched_sources_keep_their_brackets_balanced(patched_src):
+    """no rustc here: at least every file the patch touches (and the two shim files) must still nest (), [] and {} properly"""
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for f in sorted(patched_src.glob("*.rs")):
+        text = strip_rust_comments(f.read_text())
+        text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text)   # string literals
+        text = re.sub(r"'(?:\\.|[^'\\])'", "' '", text)    # char literals (lifetimes have no closing quote)
+        stack = []
+        for ch in text:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in pairs:
+                assert stack and stack.pop() == pairs[ch], f.name
+        assert not stack, f.name
+
+
+@needs_reference
+def test_every_scene_type_of_the_closed_set_describes_itself(patched_src):
+    src = {f.name: strip_rust_comments(f.read_text()) for f in patched_src.glob("*.rs")}
+    # the four traits carry the defaulted method ...
+    for fname, trait, ret in (("hitable.rs", "Hitable", "RaynHitable"), ("material.rs", "Material", "RaynMaterial"), ("light.rs", "Light", "RaynLight"),
+                              ("camera.rs", "Camera", "RaynCamera")):
+        body = re.search(r"pub trait %s\b.*?\n}\n" % trait, src[fname], re.S).group(0)
+        assert re.search(r"fn describe\(&self\) -> Option<crate::hip::%s> \{\s*None\s*\}" % ret, body), trait
+    # ... and every concrete type of the closed set overrides it inside its trait impl
+    for fname, impl_head in (("sphere.rs", r"impl<TR: WSequenced<Wec3>> Hitable for Sphere<TR>"), ("sdf.rs", r"Hitable for TracedSDF<S>"),
+                             ("material.rs", r"Material for Lambertian<AG>"), ("material.rs", r"Material for Dielectric<AG, RG>"),
+                             ("material.rs", r"impl Material for Sky"), ("material.rs", r"Material for Emissive<EG>"),
+                             ("light.rs", r"impl Light for SphereLight"), ("camera.rs", r"Camera for PinholeCamera<O, A, U>"),
+                             ("camera.rs", r"Camera for ThinLensCamera<A, O, LA, U, F>"), ("camera.rs", r"Camera for OrthographicCamera<O, A, U>")):
+        m = re.search(impl_head + r".*?\n}\n", src[fname], re.S)
+        assert m and "fn describe(&self)" in m.group(0), impl_head
+    assert "impl DescribeSdf for MandelBox" in src["sdf.rs"]
+    # every field a describe() reads exists in its struct
+    for fname, struct, fields in (("sdf.rs", "MandelBox", ["iterations", "scale_arg", "box_fold", "sphere_fold"]), ("sdf.rs", "BoxFold", ["side_length"]),
+                                  ("sdf.rs", "SphereFold", ["min_radius", "fixed_radius"]), ("light.rs", "SphereLight", ["desc"]),
+                                  ("camera.rs", "PinholeCamera", ["resolution", "vfov", "origin", "at", "up"]),
+                                  ("camera.rs", "ThinLensCamera", ["resolution", "vfov", "aperture", "origin", "at", "up", "focus"]),
+                                  ("camera.rs", "OrthographicCamera", ["resolution", "vertical_size", "origin", "at", "up"]),
+                                  ("sphere.rs", "Sphere", ["transform_seq", "radius", "material"])):
+        body = re.search(r"pub struct %s\b[^{]*\{(.*?)\n}" % struct, src[fname], re.S).group(1)
+        for fld in fields:
+            assert re.search(r"\b%s:" % fld, body), (struct, fld)
+
+
+@needs_reference
+def test_the_shim_only_uses_items_that_exist(patched_src):
+    """Every method film_hip.rs calls, every `crate::` path and every field it reads on a rayn type is defined in the patched
+    reference or in hip.rs (round 2's shim called describe() / channel_ptrs_mut that existed nowhere)."""
+    src = {f.name: strip_rust_comments(f.read_text()) for f in patched_src.glob("*.rs")}
+    shim = re.sub(r"#\[[^\]]*\]", "", src["film_hip.rs"])  # attributes are not calls
+    everything = "\n".join(src.values())
+    defined_fns = set(re.findall(r"\bfn (\w+)", everything))
+    for m in set(re.findall(r"\.(\w+)\(", shim)) | set(re.findall(r"\b(\w+)\(", shim)):
+        if m in STD_METHODS or m[0].isupper() or m in ("Some", "Ok", "Err", "drop", "vec", "match", "if", "for"):
+            continue
+        assert m in defined_fns, f"film_hip.rs calls {m}() which nothing defines"
+    # `use crate::module::{Items}` and inline crate:: paths
+    for mod, items in re.findall(r"use crate::(\w+)::\{?([\w, *]+)\}?;", shim):
+        assert mod + ".rs" in src, mod
+        for it in [i.strip() for i in items.split(",")]:
+            if it != "*":
+                # a definition, or a name handed to a defining macro (`srgbs! { Srgb => Vec3, f32, .. }`, src/spectrum.rs)
+                assert re.search(r"\b(struct|enum|trait|type|fn|const) %s\b|\b%s =>" % (it, it), src[mod + ".rs"]), (mod, it)
+    for mod, item in re.findall(r"crate::(\w+)::([A-Z_][A-Z0-9_]+)\b", shim):
+        assert re.search(r"pub(\(crate\))? const %s\b" % item, src[mod + ".rs"]), (mod, item)
+    # fields read through self / world / integrator / sample_sets / fis must be visible from another module
+    visible = {("film.rs", "res"), ("film.rs", "channels"), ("film.rs", "progressive_epoch"), ("filter.rs", "inverse_cdf"), ("sampler.rs", "samples_1d"),
+               ("sampler.rs", "samples_2d"), ("integrator.rs", "max_bounces"), ("integrator.rs", "volume_marches"), ("world.rs", "hitables"),
+               ("world.rs", "materials"), ("world.rs", "lights"), ("world.rs", "cameras"), ("world.rs", "volume_params"),
+               ("volume.rs", "coeff_scattering"), ("volume.rs", "coeff_extinction")}
+    for fname, fld in visible:
+        assert re.search(r"\.%s\b" % fld, shim), fld
+        assert re.search(r"pub(\(crate\))? %s:" % fld, src[fname]), (fname, fld)
+    # constants and helpers the describe() overrides take from hip.rs
+    hip = src["hip.rs"]
+    for name in set(re.findall(r"crate::hip::(\w+)", everything)):
+        assert re.search(r"pub (const|struct|enum|fn) %s\b" % name, hip), name
+    for setter in set(re.findall(r"\bd\.(set_\w+)\(", src["camera.rs"])):
+        assert "pub fn %s(" % setter in hip, setter
