@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold first frame through the host-buffer entry (cold_ms)")
     ap.add_argument("--fma-policy", type=int, default=0, choices=[0, 1], help="0: unfused mul_add = rayn's default build (default); 1: fused = rayn built with +fma")
     # test aids for the N>1 path on a box with fewer GPUs than ranks (never used by the driver's launch)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo stages the gather through host memory)")
@@ -109,9 +110,17 @@ def main():
     wd = wld.to_desc(cam)
     p = rayn_amd.frame_params(W, H, samples, bounces, tile_first=rank, tile_step=world)
     tabs = rayn_amd.build_tables(spp, bounces, p.volume_marches, p.frame, W, H)
+    # cold_ms: what a host that renders ONE frame per process pays - the reference's own usage (src/main.rs:47-96, frame_range 1..2):
+    # context creation -> world upload -> first frame through the HOST-buffer entry (tables up, film down) on a context with no
+    # device memory yet.  Outside the timed region; the same context then serves the warm-up and the timed steps.
+    t_cold = time.perf_counter()
     ctx = rayn_amd.Context(local_rank)
     ctx.upload_world(wd)
     ctx.set_fma_policy(args.fma_policy)
+    cold_ms = None
+    if not use_dist and not args.no_cold:
+        ctx.render_host(p, tabs)
+        cold_ms = (time.perf_counter() - t_cold) * 1e3
     d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
     film = rayn_amd.film.alloc_device_film(W, H, device)
     gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo"), force=args.force_dist) if use_dist else None
@@ -273,6 +282,7 @@ def main():
                        "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one RCCL gather of the owned pixels to rank 0 per frame" if use_dist else "")},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "kernel_ms": kernel_ms,
             "segments_per_step": segments_per_step,
+            "cold_ms": None if cold_ms is None else round(cold_ms, 1),  # fresh context -> first frame done (host buffers), see above
         }
         out["config"]["build_variant"] = rayn_amd._lib.build_variant() or "product"
         if film_check is not None:

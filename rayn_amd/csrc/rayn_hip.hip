@@ -52,6 +52,7 @@ struct Worker {
     DCtl* h_ctl = nullptr;                 // pinned: the control block read back once per frame share
     std::vector<DTile> h_tiles;            // staging of every batch's tile list (one upload per frame share)
     unsigned long long* d_evals = nullptr; // [4]
+    DCtl* d_ctl = nullptr;                 // device control block (outside the arena: the arena may be re-allocated between frames)
     hipEvent_t done = nullptr;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
@@ -78,6 +79,9 @@ struct rayn_ctx {
     bool profiling = false, counting = false;
     size_t batch_paths = (size_t)1 << 28;   // per worker; also limited by the HBM budget and the 32-bit job refs (render_device)
     size_t two_worker_min_paths = (size_t)1 << 22;
+    size_t cold_bytes = (size_t)44 << 30;   // arena size per worker of a context's FIRST frame (render_device); 0 = full size at once
+    uint64_t frames_rendered = 0;
+    float* host_stage = nullptr; size_t host_stage_cap = 0; // rayn_hip_render_frame: device copies of the caller's tables + film (grow-only)
     int n_workers = 2;
     Tuning tun;
     std::vector<uint32_t> tile_subset; // rayn_hip_set_tile_subset: render only these tiles (sorted)
@@ -294,93 +298,118 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     const KernelSet& K = F.K;
     hipStream_t stream = w->stream;
     // ---- batches of whole tiles that fit the path pool
-    std::vector<std::vector<BatchTile>> batches;
-    size_t max_pool = 0, max_tiles = 0;
-    uint32_t max_tile_pixels = 0;
-    {
+    struct Plan { std::vector<std::vector<BatchTile>> batches; size_t max_pool = 0, max_tiles = 0; };
+    auto make_plan = [&](size_t from, size_t cap_paths) { // tiles mine[from..] cut into batches of <= cap_paths pool slots
+        Plan P;
         std::vector<BatchTile> cur;
         size_t pool = 0;
-        for (const BatchTile& t : mine) {
+        for (size_t i = from; i < mine.size(); i++) {
+            const BatchTile& t = mine[i];
             size_t n = t.d.n_paths, na = (n + 63) & ~(size_t)63;
-            if (!cur.empty() && pool + na > F.batch_paths) {
-                max_pool = std::max(max_pool, pool); max_tiles = std::max(max_tiles, cur.size());
-                batches.push_back(std::move(cur)); cur.clear(); pool = 0;
+            if (!cur.empty() && pool + na > cap_paths) {
+                P.max_pool = std::max(P.max_pool, pool); P.max_tiles = std::max(P.max_tiles, cur.size());
+                P.batches.push_back(std::move(cur)); cur.clear(); pool = 0;
             }
             BatchTile bt = t;
             bt.d.pool_base = (uint32_t)pool;
             cur.push_back(bt);
             pool += na;
-            max_tile_pixels = std::max(max_tile_pixels, t.d.ew * t.d.eh);
         }
-        if (!cur.empty()) { max_pool = std::max(max_pool, pool); max_tiles = std::max(max_tiles, cur.size()); batches.push_back(std::move(cur)); }
-    }
-    // ---- device memory: one arena sized for the largest batch
-    const size_t CAP = max_pool;                                   // pool slots
-    const size_t QCAP = CAP + max_tiles * 64;                      // ray queue slots (tile tails)
-    const size_t BCAP = CAP + max_tiles * (SCAN_NC_BIN * 3 + 64);  // binned slots (x4 bin padding + tails)
-    const size_t QG = QCAP / 64 + 1, BG = BCAP / 64 + 1;
-    const size_t JOBCAP = (size_t)NS * BCAP;
-    size_t total_tiles = 0;
-    for (auto& b : batches) total_tiles += b.size();
-    // 32-bit [sample][slot] ids: k_shadow_list's grid-stride counter advances in steps of up to 2^25 ids and must not wrap
-    if (JOBCAP > ((size_t)1 << 32) - ((size_t)1 << 26) || BCAP >= ((size_t)1 << 31)) return wfail(w, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
-    size_t need = 0;
-    auto acc = [&](size_t n, size_t sz) { need += (n * sz + 255) & ~(size_t)255; };
-    for (int i = 0; i < 5; i++) acc(CAP, 16);
-    acc(CAP, 4); acc(CAP, 1);                                                                      // pool records + termination
-    acc(QCAP, 4); acc(QCAP, 4); acc(BCAP, 4); acc(QCAP, 1); acc(BCAP, 1);                          // q, qn, bq, ent_obj, alive
-    acc(QG * SCAN_NC_BIN, 1); acc(QG * SCAN_NC_BIN, 4); acc(QG, 4);                                // grp_cnt, grp_base, grp_tile
-    acc(BG, 1); acc(BG, 4); acc(BG, 4);                                                            // bgrp_*
-    acc(total_tiles, sizeof(DTile)); acc(CAP / 64 + 1, 4);                                         // tiles of every batch, pgrp_tile
-    for (int i = 0; i < 7; i++) acc(max_tiles, 4);                                                 // tgbA,tgcA,tgbB,tgcB,tile_total,tile_valid,tile_out_base
-    acc(max_tiles * SCAN_NC_BIN, 4); acc(max_tiles * SCAN_NC_BIN, 4); acc(1, sizeof(DCtl));        // tile_cls_cnt, tile_cls_base, control block
-    acc(12 * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 4); acc((NS - 4 + 1) * BCAP, 4); acc(NS * BCAP, 1); acc(BCAP, 8); // x, vtr, pdf, aux, vis, vpicks
-    acc(BCAP, 4); acc(BCAP, 4); acc(3 * BCAP, 4); acc(BCAP, 1);                                                                    // T, t0, nthr, flags
-    acc(JOBCAP, 4); acc(3 * JOBCAP, 8);
+        if (!cur.empty()) { P.max_pool = std::max(P.max_pool, pool); P.max_tiles = std::max(P.max_tiles, cur.size()); P.batches.push_back(std::move(cur)); }
+        return P;
+    };
+    uint32_t max_tile_pixels = 0;
+    for (const BatchTile& t : mine) max_tile_pixels = std::max(max_tile_pixels, t.d.ew * t.d.eh);
+    const size_t total_tiles = mine.size();
+    // ---- device memory: one arena carved for the largest batch of a plan
+    struct Layout {
+        size_t CAP = 0, QCAP = 0, BCAP = 0, JOBCAP = 0;
+        Pool pool; uint32_t *q, *qn, *bq; uint8_t *ent_obj, *alive;
+        uint8_t* grp_cnt; uint32_t *grp_base, *grp_tile; uint8_t* bgrp_cnt; uint32_t *bgrp_base, *bgrp_tile;
+        DTile* d_all_tiles; uint32_t* pgrp_tile;
+        uint32_t *tgbA, *tgcA, *tgbB, *tgcB, *tile_total, *tile_valid, *tile_out_base, *tile_cls_cnt, *tile_cls_base;
+        Nee nee;
+    };
+    // sizes (dry = true: only A.off advances) or carves the arena for batches of <= CAP pool slots in <= max_tiles tiles
+    auto carve = [&](Arena& A, size_t CAP, size_t max_tiles, Layout* L) {
+        L->CAP = CAP;
+        L->QCAP = CAP + max_tiles * 64;                      // ray queue slots (tile tails)
+        L->BCAP = CAP + max_tiles * (SCAN_NC_BIN * 3 + 64);  // binned slots (x4 bin padding + tails)
+        L->JOBCAP = (size_t)NS * L->BCAP;
+        const size_t QCAP = L->QCAP, BCAP = L->BCAP, JOBCAP = L->JOBCAP, QG = QCAP / 64 + 1, BG = BCAP / 64 + 1;
+        A.off = 0;
+        Pool& pool = L->pool;
+        pool.geo0 = A.take<float4>(CAP); pool.geo1 = A.take<float4>(CAP); pool.col0 = A.take<float4>(CAP); pool.col1 = A.take<float4>(CAP);
+        pool.aov = A.take<float4>(CAP); pool.term_key = A.take<uint32_t>(CAP); pool.term_info = A.take<uint8_t>(CAP);
+        L->q = A.take<uint32_t>(QCAP); L->qn = A.take<uint32_t>(QCAP); L->bq = A.take<uint32_t>(BCAP);
+        L->ent_obj = A.take<uint8_t>(QCAP); L->alive = A.take<uint8_t>(BCAP);
+        L->grp_cnt = A.take<uint8_t>(QG * SCAN_NC_BIN); L->grp_base = A.take<uint32_t>(QG * SCAN_NC_BIN); L->grp_tile = A.take<uint32_t>(QG);
+        L->bgrp_cnt = A.take<uint8_t>(BG); L->bgrp_base = A.take<uint32_t>(BG); L->bgrp_tile = A.take<uint32_t>(BG);
+        L->d_all_tiles = A.take<DTile>(total_tiles); L->pgrp_tile = A.take<uint32_t>(CAP / 64 + 1);
+        L->tgbA = A.take<uint32_t>(max_tiles); L->tgcA = A.take<uint32_t>(max_tiles);
+        L->tgbB = A.take<uint32_t>(max_tiles); L->tgcB = A.take<uint32_t>(max_tiles);
+        L->tile_total = A.take<uint32_t>(max_tiles); L->tile_valid = A.take<uint32_t>(max_tiles); L->tile_out_base = A.take<uint32_t>(max_tiles);
+        L->tile_cls_cnt = A.take<uint32_t>(max_tiles * SCAN_NC_BIN); L->tile_cls_base = A.take<uint32_t>(max_tiles * SCAN_NC_BIN);
+        Nee& nee = L->nee;
+        nee.cap = BCAP; nee.jobcap = JOBCAP;
+        nee.x = A.take<float>(12 * BCAP); nee.vtr = A.take<float>((NS - 4 + 1) * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
+        nee.vis = A.take<uint8_t>(NS * BCAP); nee.vpicks = A.take<unsigned long long>(BCAP);
+        nee.T = A.take<float>(BCAP); nee.t0 = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
+        nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float2>(3 * JOBCAP);
+        return A.off;
+    };
+    auto need_of = [&](const Plan& P) { Arena dry; Layout l; return carve(dry, P.max_pool, P.max_tiles, &l); };
+    auto fits32 = [&](const Plan& P) { // 32-bit [sample][slot] ids: k_shadow_list's grid-stride counter advances in steps of up to 2^25 ids and must not wrap
+        const size_t BCAP = P.max_pool + P.max_tiles * (SCAN_NC_BIN * 3 + 64);
+        return (size_t)NS * BCAP <= ((size_t)1 << 32) - ((size_t)1 << 26) && BCAP < ((size_t)1 << 31);
+    };
+    Plan plan = make_plan(0, F.batch_paths);
+    if (!fits32(plan)) return wfail(w, RAYN_ERR_INVALID_ARG, "batch too large for 32-bit queue indices; lower RAYN_HIP_BATCH_PATHS");
+    const size_t need = need_of(plan);
     if (need > w->arena.cap) {
-        if (w->arena.base) WCHK(hipFree(w->arena.base));
-        w->arena.base = nullptr; w->arena.cap = 0;
+        // grow: the new arena is obtained BEFORE the old one is released, so that it comes out of memory the driver does not have
+        // to wipe first (freshly freed device memory is, see render_device) whenever that much is free
         void* ptr = nullptr;
-        if (hipMalloc(&ptr, need) != hipSuccess) return wfail(w, RAYN_ERR_OOM, "hipMalloc of the path pool failed (" + std::to_string(need >> 20) + " MiB)");
+        if (hipMalloc(&ptr, need) != hipSuccess) {
+            (void)hipGetLastError();
+            if (w->arena.base) { WCHK(hipFree(w->arena.base)); w->arena = Arena(); }
+            if (hipMalloc(&ptr, need) != hipSuccess) return wfail(w, RAYN_ERR_OOM, "hipMalloc of the path pool failed (" + std::to_string(need >> 20) + " MiB)");
+        }
+        if (w->arena.base) WCHK(hipFree(w->arena.base));
         w->arena.base = (char*)ptr; w->arena.cap = need;
     }
-    Arena& A = w->arena;
-    A.off = 0;
-    Pool pool;
-    pool.geo0 = A.take<float4>(CAP); pool.geo1 = A.take<float4>(CAP); pool.col0 = A.take<float4>(CAP); pool.col1 = A.take<float4>(CAP);
-    pool.aov = A.take<float4>(CAP); pool.term_key = A.take<uint32_t>(CAP); pool.term_info = A.take<uint8_t>(CAP);
-    uint32_t* q = A.take<uint32_t>(QCAP); uint32_t* qn = A.take<uint32_t>(QCAP); uint32_t* bq = A.take<uint32_t>(BCAP);
-    uint8_t* ent_obj = A.take<uint8_t>(QCAP); uint8_t* alive = A.take<uint8_t>(BCAP);
-    uint8_t* grp_cnt = A.take<uint8_t>(QG * SCAN_NC_BIN); uint32_t* grp_base = A.take<uint32_t>(QG * SCAN_NC_BIN); uint32_t* grp_tile = A.take<uint32_t>(QG);
-    uint8_t* bgrp_cnt = A.take<uint8_t>(BG); uint32_t* bgrp_base = A.take<uint32_t>(BG); uint32_t* bgrp_tile = A.take<uint32_t>(BG);
-    DTile* d_all_tiles = A.take<DTile>(total_tiles); uint32_t* pgrp_tile = A.take<uint32_t>(CAP / 64 + 1);
-    uint32_t* tgbA = A.take<uint32_t>(max_tiles); uint32_t* tgcA = A.take<uint32_t>(max_tiles);
-    uint32_t* tgbB = A.take<uint32_t>(max_tiles); uint32_t* tgcB = A.take<uint32_t>(max_tiles);
-    uint32_t* tile_total = A.take<uint32_t>(max_tiles); uint32_t* tile_valid = A.take<uint32_t>(max_tiles); uint32_t* tile_out_base = A.take<uint32_t>(max_tiles);
-    uint32_t* tile_cls_cnt = A.take<uint32_t>(max_tiles * SCAN_NC_BIN); uint32_t* tile_cls_base = A.take<uint32_t>(max_tiles * SCAN_NC_BIN);
-    DCtl* d_ctl = A.take<DCtl>(1);
-    Nee nee;
-    nee.cap = BCAP; nee.jobcap = JOBCAP;
-    nee.x = A.take<float>(12 * BCAP); nee.vtr = A.take<float>((NS - 4 + 1) * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
-    nee.vis = A.take<uint8_t>(NS * BCAP); nee.vpicks = A.take<unsigned long long>(BCAP);
-    nee.T = A.take<float>(BCAP); nee.t0 = A.take<float>(BCAP); nee.nthr = A.take<float>(3 * BCAP); nee.flags = A.take<uint8_t>(BCAP);
-    nee.job_ref = A.take<uint32_t>(JOBCAP); nee.job_geo = A.take<float2>(3 * JOBCAP);
-    if (A.off > A.cap) return wfail(w, RAYN_ERR_OOM, "internal: arena under-sized");
+    Arena* A = &w->arena;
+    Layout L;
+    if (carve(*A, plan.max_pool, plan.max_tiles, &L) > A->cap) return wfail(w, RAYN_ERR_OOM, "internal: arena under-sized");
+    DCtl* d_ctl = w->d_ctl;
 
-    // The whole share is ENQUEUED without a single host<->device round trip: queue sizes live in d_ctl, the tile lists of all
-    // batches go up in one copy (the staging vector belongs to the worker and outlives the copy), kernels size themselves.
+    // The whole share is ENQUEUED without a single host<->device round trip: queue sizes live in d_ctl,
+    // every batch's tile list goes up with one small copy (the staging vector belongs to the worker, is reserved up front and
+    // outlives the copies), kernels size themselves.
     w->h_tiles.clear();
-    for (auto& batch : batches) for (auto& bt : batch) w->h_tiles.push_back(bt.d);
-    WCHK(hipMemcpyAsync(d_all_tiles, w->h_tiles.data(), total_tiles * sizeof(DTile), hipMemcpyHostToDevice, stream));
+    w->h_tiles.reserve(total_tiles);
     WCHK(hipMemsetAsync(d_ctl, 0, sizeof(DCtl), stream));
     WCHK(hipMemsetAsync(w->d_evals, 0, 32, stream));
     const bool count = F.count, prof = F.profiling;
     const Tables& tab = F.tab;
     const uint32_t last_depth = F.p->max_bounces; // a path that reaches depth == max_bounces terminates there (src/integrator.rs:171)
-    size_t tile_cursor = 0;
-    for (auto& batch : batches) {
+    size_t tile_cursor = 0; // tiles enqueued so far = index into mine / d_all_tiles
+    for (size_t bi = 0; bi < plan.batches.size(); bi++) {
+        std::vector<BatchTile>& batch = plan.batches[bi];
+        Pool& pool = L.pool; Nee& nee = L.nee;
+        uint32_t *q = L.q, *qn = L.qn, *bq = L.bq; uint8_t *ent_obj = L.ent_obj, *alive = L.alive;
+        uint8_t* grp_cnt = L.grp_cnt; uint32_t *grp_base = L.grp_base, *grp_tile = L.grp_tile;
+        uint8_t* bgrp_cnt = L.bgrp_cnt; uint32_t *bgrp_base = L.bgrp_base, *bgrp_tile = L.bgrp_tile;
+        uint32_t *pgrp_tile = L.pgrp_tile, *tgbA = L.tgbA, *tgcA = L.tgcA, *tgbB = L.tgbB, *tgcB = L.tgcB;
+        uint32_t *tile_total = L.tile_total, *tile_valid = L.tile_valid, *tile_out_base = L.tile_out_base, *tile_cls_cnt = L.tile_cls_cnt, *tile_cls_base = L.tile_cls_base;
+        const size_t BCAP = L.BCAP, QCAP = L.QCAP;
         const uint32_t nt = (uint32_t)batch.size();
-        const DTile* d_tiles = d_all_tiles + tile_cursor;
+        DTile* d_tiles = L.d_all_tiles + tile_cursor;
+        {
+            const size_t h0 = w->h_tiles.size();
+            for (auto& bt : batch) w->h_tiles.push_back(bt.d);
+            WCHK(hipMemcpyAsync(d_tiles, w->h_tiles.data() + h0, (size_t)nt * sizeof(DTile), hipMemcpyHostToDevice, stream));
+        }
         tile_cursor += nt;
         size_t n_pool = 0;
         for (uint32_t i = 0; i < nt; i++) {
@@ -552,10 +581,19 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         for (int c = std::max(max_w, 1); c >= 1; c--) {
             // 32-bit [sample][slot] refs: NS * (binned slots of a batch) must stay below 2^32 (5 % slack for bin padding and tile tails)
             const size_t index_cap = (size_t)(0.95 * 4294967296.0 / (double)F.NS);
-            const size_t cap = std::max<size_t>(4096, std::min(std::min(ctx->batch_paths, index_cap), budget_paths / (size_t)c));
+            // FIRST FRAME of a context: arenas of at most cold_bytes per worker (44 GB: 2^26-path batches with the volume path's
+            // 667 B per path, 2^27 without).  The reference renders ONE frame per process
+            // (src/main.rs:47-96) - a render farm runs such processes back to back - and device memory that a process released is
+            // wiped by the driver before the next one can use it: measured (tools/cold_frame.py, profiles/r03_cold_start.txt), a
+            // fresh process whose first frame takes a 175 GB arena runs that frame 3.5 s longer when it starts right after a
+            // process of the same size (+1.0-1.2 s at 87-104 GB, +0.0 s after a 6 s pause; obtaining the arena on a side thread
+            // does not hide it - the running kernels stall too).  A quarter of the memory costs 2.5 % of steady-state speed; a
+            // context that renders a second frame grows to the full size then.
+            const size_t first = (ctx->frames_rendered == 0 && ctx->cold_bytes) ? ctx->cold_bytes / per_path : ~(size_t)0;
+            const size_t cap = std::max<size_t>(4096, std::min(first, std::min(std::min(ctx->batch_paths, index_cap), budget_paths / (size_t)c)));
             // a further worker must not cost batch size: with c workers each still gets >= 3/4 of the batch one worker would get
             // (config 3, 651 B per path: one worker with 2^28-path batches beats two with 2^27; config 2, 331 B: both fit)
-            const size_t solo = std::max<size_t>(4096, std::min(std::min(ctx->batch_paths, index_cap), budget_paths));
+            const size_t solo = std::max<size_t>(4096, std::min(first, std::min(std::min(ctx->batch_paths, index_cap), budget_paths)));
             if (c == 1 || (owned_paths >= ctx->two_worker_min_paths && owned_paths >= (size_t)c * cap && 4 * cap >= 3 * solo) ||
                 (ctx->two_worker_min_paths == 0)) { nw = c; F.batch_paths = cap; break; }
         }
@@ -590,6 +628,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     (void)hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
     ctx->stats.ms_total = ms;
     if (ctx->profiling) collect_profile(ctx);
+    ctx->frames_rendered++;
     return RAYN_OK;
 }
 
@@ -761,11 +800,13 @@ int rayn_hip_create(int device, rayn_ctx** out) {
               hipEventCreate(&ctx->ev_b) == hipSuccess && hipEventCreate(&ctx->ev_ma) == hipSuccess && hipEventCreate(&ctx->ev_mb) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (Worker& w : ctx->workers)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess && hipMalloc((void**)&w.d_evals, 32) == hipSuccess &&
+             hipMalloc((void**)&w.d_ctl, sizeof(DCtl)) == hipSuccess &&
              hipHostMalloc((void**)&w.h_totals, 16) == hipSuccess && hipHostMalloc((void**)&w.h_ctl, sizeof(DCtl)) == hipSuccess && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { rayn_hip_destroy(ctx); return RAYN_ERR_HIP; }
     if (const char* e = getenv("RAYN_HIP_WORKERS")) ctx->n_workers = atoi(e);
     if (const char* e = getenv("RAYN_HIP_WORKER_MIN_PATHS")) ctx->two_worker_min_paths = (size_t)atoll(e); // 0 forces n_workers
     if (const char* e = getenv("RAYN_HIP_BATCH_PATHS")) { long long v = atoll(e); if (v >= 4096) ctx->batch_paths = (size_t)v; }
+    if (const char* e = getenv("RAYN_HIP_COLD_BYTES")) { long long v = atoll(e); ctx->cold_bytes = v > 0 ? (size_t)v : 0; }
     if (const char* e = getenv("RAYN_HIP_PROFILE")) ctx->profiling = atoi(e) != 0;
     if (const char* e = getenv("RAYN_HIP_REFILL_EXTEND")) ctx->tun.refill_min_extend = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("RAYN_HIP_REFILL_SHADOW")) ctx->tun.refill_min_shadow = (uint32_t)std::max(1, atoi(e));
@@ -831,6 +872,7 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
     for (Worker& w : ctx->workers) {
         if (w.stream) (void)hipStreamSynchronize(w.stream);
         for (auto e : w.event_pool) (void)hipEventDestroy(e);
+        if (w.d_ctl) (void)hipFree(w.d_ctl);
         if (w.arena.base) (void)hipFree(w.arena.base);
         if (w.d_evals) (void)hipFree(w.d_evals);
         if (w.h_totals) (void)hipHostFree(w.h_totals);
@@ -839,6 +881,7 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     if (ctx->d_rec) (void)hipFree(ctx->d_rec);
+    if (ctx->host_stage) (void)hipFree(ctx->host_stage);
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
@@ -880,22 +923,30 @@ int rayn_hip_render_frame(rayn_ctx* ctx, const rayn_frame_params* p, const float
     HIPCHK(hipSetDevice(ctx->device));
     const size_t spp = (size_t)p->samples * 4, npx = (size_t)p->width * p->height;
     const size_t n1 = spp * rayn_sets_1d(p->max_bounces, p->volume_marches), n2 = spp * 2 * rayn_sets_2d(p->max_bounces, p->volume_marches);
-    float* d = nullptr;
+    // device copies of the caller's buffers: one grow-only allocation kept by the context (no hipMalloc / hipFree per frame)
     const size_t total = n1 + n2 + npx + RAYN_FIS_TABLE_SIZE + npx * RAYN_FILM_FLOATS_PER_PIXEL;
-    if (hipMalloc((void**)&d, total * 4) != hipSuccess) return fail(ctx, RAYN_ERR_OOM, "hipMalloc of tables + film failed");
+    rc = ensure(ctx, &ctx->host_stage, &ctx->host_stage_cap, total);
+    if (rc) return rc;
+    float* d = ctx->host_stage;
     float *d1 = d, *d2 = d1 + n1, *dscr = d2 + n2, *dfis = dscr + npx, *dc = dfis + RAYN_FIS_TABLE_SIZE, *da = dc + 3 * npx, *db = da + npx, *dn = db + 3 * npx;
     hipError_t e = hipSuccess;
-    auto up = [&](float* dst, const float* src, size_t n) { if (e == hipSuccess) e = hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice); };
+    auto up = [&](float* dst, const float* src, size_t n) { if (e == hipSuccess) e = hipMemcpyAsync(dst, src, n * 4, hipMemcpyHostToDevice, ctx->stream); };
     up(d1, samples_1d, n1); up(d2, samples_2d, n2); up(dscr, scramble, npx); up(dfis, fis_table, RAYN_FIS_TABLE_SIZE);
-    up(dc, out_color, 3 * npx); up(da, out_alpha, npx); up(db, out_background, 3 * npx); up(dn, out_normal, 3 * npx); // keep un-owned pixels
-    if (e != hipSuccess) { hipFree(d); return fail(ctx, RAYN_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); }
+    // The film goes up first only when the call leaves some of its pixels alone (a tile share, a tile subset, or a resolution the
+    // reference's tile grid under-covers, src/film.rs:399-427): Film::render_frame_into overwrites every pixel of every tile it runs
+    // (src/film.rs:82-98), so a whole-frame call - what src/main.rs does - has nothing to preserve (82.9 MB at 1920x1080, 1.33 GB at 8K).
+    const bool covers = (p->width + p->width % p->tile_w) / p->tile_w * (uint64_t)p->tile_w >= p->width &&
+                        (p->height + p->height % p->tile_h) / p->tile_h * (uint64_t)p->tile_h >= p->height;
+    const bool owns_all = covers && p->tile_step <= 1 && ctx->tile_subset.empty();
+    if (!owns_all) { up(dc, out_color, 3 * npx); up(da, out_alpha, npx); up(db, out_background, 3 * npx); up(dn, out_normal, 3 * npx); }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // the host tables may change as soon as this call returns; pageable sources are staged by the runtime
+    if (e != hipSuccess) return fail(ctx, RAYN_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
     rc = render_any(ctx, p, d1, d2, dscr, dfis, dc, da, db, dn, ctx->stream);
     if (rc == RAYN_OK) {
         auto down = [&](float* dst, const float* src, size_t n) { if (e == hipSuccess) e = hipMemcpy(dst, src, n * 4, hipMemcpyDeviceToHost); };
         down(out_color, dc, 3 * npx); down(out_alpha, da, npx); down(out_background, db, 3 * npx); down(out_normal, dn, 3 * npx);
         if (e != hipSuccess) rc = fail(ctx, RAYN_ERR_HIP, std::string("download: ") + hipGetErrorString(e));
     }
-    hipFree(d);
     return rc;
 }
 
@@ -923,6 +974,13 @@ int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths) {
     if (!ctx || paths < 4096) return RAYN_ERR_INVALID_ARG;
     ctx->batch_paths = (size_t)paths;
     for (rayn_ctx* c : ctx->peers) c->batch_paths = (size_t)paths;
+    return RAYN_OK;
+}
+
+int rayn_hip_set_cold_bytes(rayn_ctx* ctx, uint64_t bytes) {
+    if (!ctx) return RAYN_ERR_INVALID_ARG;
+    ctx->cold_bytes = (size_t)bytes;
+    for (rayn_ctx* c : ctx->peers) c->cold_bytes = (size_t)bytes;
     return RAYN_OK;
 }
 

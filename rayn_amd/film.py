@@ -104,6 +104,10 @@ class Context:
     def set_batch_paths(self, n):
         self._chk(self._L.rayn_hip_set_batch_paths(self.h, int(n)))
 
+    def set_cold_bytes(self, n):
+        """arena bytes per worker of the context's first frame (rayn_hip_set_cold_bytes); 0 = full-size batches from the first frame"""
+        self._chk(self._L.rayn_hip_set_cold_bytes(self.h, int(n)))
+
     def stats(self):
         s = _abi.Stats()
         self._chk(self._L.rayn_hip_get_stats(self.h, C.byref(s)))

@@ -246,6 +246,54 @@ def test_batching_is_invisible(gpu_ctx, oracle):
     assert film_equal_bits(a, b)
 
 
+def test_first_frame_batching_is_invisible(oracle):
+    """The first frame of a context runs in batches sized for a small arena (rayn_hip_set_cold_bytes), later frames in
+    full-size batches out of a re-allocated arena: same bits as the oracle on both, with one and two workers, and with the policy off."""
+    import rayn_amd
+    wd, p = case("s2", 96, 64, 2, 3)  # 24 tiles of 2048 paths
+    tabs = _tables(oracle, p)
+    ref, ctr = oracle.render(wd, p, tabs)
+    for workers, cold in ((1, 4096 * 700), (2, 4096 * 700), (1, 0)):  # 667 B per path with the volume path: 4298-path batches
+        ctx = rayn_amd.Context(0)
+        try:
+            ctx.upload_world(wd)
+            ctx.set_workers(workers, 0)
+            ctx.set_cold_bytes(cold)
+            first = ctx.render_host(p, tabs)
+            st = ctx.stats()
+            assert st["paths"] == ctr.paths and st["segments"] == ctr.segments
+            assert st["batches"] == (12 if cold else workers), st["batches"]  # two 2048-path tiles per batch
+            assert film_equal_bits(first, ref)
+            second = ctx.render_host(p, tabs)  # full-size batches: one per worker, arena grown
+            assert ctx.stats()["batches"] == workers
+            assert film_equal_bits(second, ref)
+        finally:
+            ctx.close()
+
+
+def test_host_entry_preserves_unowned_pixels_only_when_there_are_any(gpu_ctx, oracle):
+    """rayn_hip_render_frame uploads the caller's film only when the call leaves pixels alone (a tile share): those keep the
+    caller's values; a whole-frame call overwrites every pixel without reading the caller's buffer."""
+    wd, p = case("s1", 64, 48, 1, 2)
+    tabs = _tables(oracle, p)
+    ref, _ = oracle.render(wd, p, tabs)
+    gpu_ctx.upload_world(wd)
+    n = p.width * p.height
+    mark = lambda: {"color": np.full((n, 3), 7.0, np.float32), "alpha": np.full(n, 7.0, np.float32), "background": np.full((n, 3), 7.0, np.float32),
+                    "normal": np.full((n, 3), 7.0, np.float32)}
+    whole = gpu_ctx.render_host(p, tabs, out=mark())
+    assert film_equal_bits(whole, ref)
+    _, half = case("s1", 64, 48, 1, 2, tile_first=1, tile_step=2)
+    part = gpu_ctx.render_host(half, tabs, out=mark())
+    owned = np.zeros((p.height, p.width), bool)
+    from rayn_amd.distributed import owned_pixels
+    owned.reshape(-1)[owned_pixels(p.width, p.height, p.tile_w, p.tile_h, 1, 2)] = True
+    assert owned.any() and not owned.all()
+    assert np.array_equal(part["alpha"][owned].view(np.uint32), ref["alpha"][owned].view(np.uint32))
+    assert np.array_equal(part["color"][owned].view(np.uint32), ref["color"][owned].view(np.uint32))
+    assert (part["alpha"][~owned] == 7.0).all() and (part["color"][~owned] == 7.0).all()
+
+
 def test_two_workers_are_invisible(gpu_ctx, oracle):
     """The two-worker pipeline (two host threads / streams) on a small frame, with several batches per worker."""
     wd, p = case("s2", 64, 48, 2, 3)

@@ -32,7 +32,9 @@ __global__ void k_spin(float* out, int iters) { // VALU-bound busy kernel
     if (a == 12345.0f) out[0] = a + b;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const bool do_vmm = argc > 1 && atoi(argv[1]) != 0; // VMM stages only on request
     CK(hipSetDevice(0));
     size_t fr, tot; CK(hipMemGetInfo(&fr, &tot));
     printf("free %.1f GB of %.1f GB\n", fr / 1e9, tot / 1e9);
@@ -61,7 +63,7 @@ int main() {
     printf("VMM granularity (recommended) %zu bytes\n", gran);
     const size_t RANGE = (size_t)128 << 30;
     void* va = nullptr;
-    { double t0 = now(); hipError_t e = hipMemAddressReserve(&va, RANGE, 0, nullptr, 0); printf("hipMemAddressReserve 128 GB: %.3f ms (%s)\n", now() - t0, hipGetErrorString(e)); if (e != hipSuccess) va = nullptr; }
+    if (do_vmm) { double t0 = now(); hipError_t e = hipMemAddressReserve(&va, RANGE, 0, nullptr, 0); printf("hipMemAddressReserve 128 GB: %.3f ms (%s)\n", now() - t0, hipGetErrorString(e)); if (e != hipSuccess) va = nullptr; }
     std::vector<hipMemGenericAllocationHandle_t> handles;
     size_t mapped = 0;
     auto map_chunk = [&](size_t bytes, bool verbose) -> bool {
