@@ -41,8 +41,11 @@ struct Vec3 {
     Vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
     static Vec3 zero() { return Vec3(0, 0, 0); }
     Vec3 operator*(float s) const { return Vec3(x * s, y * s, z * s); }
-    Vec3 normalized() const { // ultraviolet: v * (1 / mag), mag_sq = x*x + (y*y + z*z)
-        float m2 = x * x + (y * y + z * z);
+    // ultraviolet's SCALAR Vec3 (oracle assumption A4/A9): mag_sq = x.mul_add(x, y.mul_add(y, z * z)), v * (1 / mag).  Rust's scalar
+    // f32::mul_add is ALWAYS a fused multiply-add (libm fmaf when the target has no FMA unit) - under both build policies of the
+    // wide types - so the host mirror uses std::fmaf unconditionally (src/setup.rs:100-101 is the call site of the shipped scene).
+    Vec3 normalized() const {
+        float m2 = std::fmaf(x, x, std::fmaf(y, y, z * z));
         float r = 1.0f / std::sqrt(m2);
         return Vec3(x * r, y * r, z * r);
     }

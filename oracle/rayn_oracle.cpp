@@ -44,6 +44,14 @@
  *      expansion's word order and the float conversion remain assumptions.
  *   A8 f32::signum(+-0) = +-1, NaN -> NaN; `as usize` saturates (NaN -> 0); light indices are
  *      clamped to n_lights-1 where the reference would panic on an out-of-range index.
+ *   A9 SCALAR arithmetic in scene construction: Rust's scalar f32::mul_add is always a fused multiply-add (std uses libm's fmaf
+ *      when the target has no FMA unit), independent of A1's policy for the wide types.  If ultraviolet's scalar Vec3 shares
+ *      the mul_add forms of A4 (unverified), Vec3::mag_sq / dot / normalized are fused on the host under BOTH policies.  The
+ *      only scalar Vec3 call sites on the shipped scene's path are the two Srgb::normalized() of src/setup.rs:100-101 (the
+ *      commented-out sun at src/setup.rs:88-97 would add a Vec3::normalized); everything else in src/setup.rs:46-170 is
+ *      f32 * / + - and tan().  This file never sees them: it consumes the flattened POD.  The host mirrors that build the POD
+ *      (rayn_amd/scene.py normalized(), include/rayn_host.hpp Vec3::normalized) evaluate the fused form unconditionally; for
+ *      the shipped constants every product is exact, so the POD is the same either way (tests/test_oracle.py).
  */
 #include "../include/rayn_detmath.h"
 #define DMF_COUNT_FALLBACKS /* host check of the kernels' fast elementary functions (oracle_detmath_fast); the oracle's path does not use them */

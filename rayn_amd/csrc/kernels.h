@@ -28,7 +28,10 @@ struct Nee {
     float* vtr;    // [ns-4][cap] volume samples: transmission sample point -> light (x = Le * 1/(4 pi) * vtr is rebuilt by k_shade_finish)
     float* pdf;    // [ns][cap]
     float* aux;    // [ns-4][cap] volume samples: exp(-rho_t * sample distance)
-    uint8_t* vis;  // [ns][cap]   HitableStore::test_occluded: 0 occluded, 1 visible, 2 SDF march pending
+    uint8_t* vis;  // [ns][cap]   HitableStore::test_occluded: 0 occluded, 1 visible, 2 SDF march pending.  The shadow kernels only write
+                   //             VISIBLE results (1): ~90 % of the marched segments of the shipped scene are occluded, and a pending mark left
+                   //             in place reads as occluded in k_shade_finish - a tenth of the scattered byte stores (r2: 151 GB written per
+                   //             config-3 frame for 40 GB of results)
     unsigned long long* vpicks; // [cap] light index of every volume sample, 4 bits each (sample 4 + k at bits 4k..4k+3)
     float* T;      // [cap]       volume transmission of the segment
     float* t0;     // [cap]       lane-0 ray time of the packet (only written / read when a hitable is time-sequenced)

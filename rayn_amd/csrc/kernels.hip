@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
                     if (m == sc.max_vis_marches || (t > max_dist) || nan) res = 1;
                 }
             }
-            if (res == 0) { nee.vis[ref] = 0; has = false; }
+            if (res == 0) has = false; // occluded: the byte keeps its 'pending' mark, which k_shade_finish reads as occluded
             else if (res == 1) { k++; next_sdf(); }
         }
     }
@@ -1074,7 +1074,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                     if (m == max_vis || (t > max_dist) || nan) res = 1;
                 }
             }
-            if (res >= 0) { nee.vis[ref] = (uint8_t)res; c_has = false; }
+            if (res >= 0) { if (res == 1) nee.vis[ref] = 1; c_has = false; } // only VISIBLE results are written (see Nee::vis)
         }
     }
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
@@ -1098,7 +1098,7 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
             const float corr = (float)nl / 4.0f, vol_T = nee.T[j];
             for (uint32_t i = 0; i < 4; i++) {
                 const f3 x = f3{nee.x[(i * 3 + 0) * cap + j], nee.x[(i * 3 + 1) * cap + j], nee.x[(i * 3 + 2) * cap + j]};
-                const float occ = (float)nee.vis[i * cap + j];
+                const float occ = nee.vis[i * cap + j] == 1 ? 1.0f : 0.0f;
                 const f3 li = x * occ / nee.pdf[i * cap + j];
                 rad = rad + li * thr * corr * vol_T;
             }
@@ -1111,7 +1111,7 @@ __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__
                 // k_shade_setup kept the transmittance, so x is rebuilt here with the same two multiplies
                 const float f = 1.0f / (4.0f * PI_F);
                 const f3 x = sc.l[(uint32_t)(vpicks >> (4 * (s - 4))) & 15u].emission * f * nee.vtr[(s - 4) * cap + j];
-                const float occ = (float)nee.vis[s * cap + j];
+                const float occ = nee.vis[s * cap + j] == 1 ? 1.0f : 0.0f;
                 const f3 li = x * occ / nee.pdf[s * cap + j];
                 rad = rad + li * thr * corr * sc.rho_s * nee.aux[(s - 4) * cap + j];
             }

@@ -32,10 +32,27 @@ def _mul(v, s):  # Vec3 * f32
     return (np.asarray(v, dtype=np.float32) * f32(s)).astype(np.float32)
 
 
+def _fmaf(a, b, c):
+    """IEEE fusedMultiplyAdd in binary32, exactly: the product of two binary32 values is exact in binary64 (48 significant bits),
+    the sum with c is formed exactly as a ratio of integers and rounded ONCE to binary32 (no double rounding through binary64)."""
+    from fractions import Fraction
+    a, b, c = float(f32(a)), float(f32(b)), float(f32(c))
+    if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+        return f32(a * b + c)
+    exact = Fraction(a) * Fraction(b) + Fraction(c)
+    lo = f32(float(exact))  # rounded through binary64: right except when it sits next to a binary32 rounding tie
+    cands = sorted({lo, np.nextafter(lo, f32(-np.inf)), np.nextafter(lo, f32(np.inf))}, key=float)
+    best = min(cands, key=lambda x: (abs(Fraction(float(x)) - exact), int(np.float32(x).view(np.uint32)) & 1))  # nearest, ties to even
+    return f32(best)
+
+
 def normalized(v):
-    """ultraviolet Vec3::normalized (oracle assumption A4): v * (1 / sqrt(x*x + (y*y + z*z)))."""
+    """ultraviolet's scalar Vec3::normalized (oracle assumptions A4 + A9): mag_sq = x.mul_add(x, y.mul_add(y, z*z)), then
+    v * (1 / sqrt(mag_sq)).  Rust's scalar f32::mul_add is ALWAYS fused (libm fmaf without an FMA unit), whatever the build
+    policy of the wide types is - src/setup.rs:100-101 normalises the light colours of the shipped scene this way (all of its
+    products happen to be exact, so the constants are the same either way; an arbitrary scene's are not)."""
     v = np.asarray(v, dtype=np.float32)
-    m2 = f32(v[0] * v[0]) + f32(f32(v[1] * v[1]) + f32(v[2] * v[2]))
+    m2 = _fmaf(v[0], v[0], _fmaf(v[1], v[1], f32(v[2] * v[2])))
     r_mag = f32(1.0) / np.sqrt(f32(m2), dtype=np.float32)
     return (v * r_mag).astype(np.float32)
 

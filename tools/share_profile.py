@@ -13,8 +13,12 @@ tabs = rayn_amd.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W,
 ctx = rayn_amd.Context(0); ctx.upload_world(w.to_desc(cam))
 d = [torch.from_numpy(t).cuda() for t in tabs]
 film = rayn_amd.film.alloc_device_film(W, H, "cuda:0")
-ctx.render_device(p, d, film); torch.cuda.synchronize()
-t = time.perf_counter(); ctx.render_device(p, d, film); torch.cuda.synchronize(); wall = (time.perf_counter() - t) * 1e3
+for _ in range(2):  # the first frame of a context runs in small batches (cold-start policy), the second grows the arenas
+    ctx.render_device(p, d, film); torch.cuda.synchronize()
+walls = []
+for _ in range(2):
+    t = time.perf_counter(); ctx.render_device(p, d, film); torch.cuda.synchronize(); walls.append((time.perf_counter() - t) * 1e3)
+wall = min(walls)
 ctx.set_workers(1); ctx.set_profiling(True, False)
 ctx.render_device(p, d, film); torch.cuda.synchronize()
 st = ctx.stats()
