@@ -209,35 +209,36 @@ def main():
             "k_resolve": (st["ms_resolve"], 37.0 * npool + 40.0 * W * H / world),  # col0 + aov + termination record per path, film out
         }
         qk["k_shadow1 (queue side: 4 B ref + 32 B segment in, 1 B visibility out per shadow job; the kernel itself is VALU-bound)"] = (st["ms_shadow"], 37.0 * st["shadow_jobs"])
-        ns_vol = 4 * p.volume_marches if wd.has_scattering else 0
-        # finish side of the NEE-record round trip, per valid segment: slot ref 4 + flags 1 + pool in/out 48 + T 4 + new throughput 12
-        # + per light sample (x 12, pdf 4, visibility 1) + 4 per volume sample (transmittance to the sample point); surface records
-        # only exist for light-receiving hits, so this is an upper estimate of the algorithmic bytes
-        qk["k_shade_finish (upper estimate)"] = (st["ms_finish"], float(st["segments"]) * (69 + (4 + ns_vol) * 17 + ns_vol * 4))
         roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shadow_jobs": st["shadow_jobs"], "kernels": {}}
         for name, (ms_k, nbytes) in qk.items():
             ach = nbytes / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
             roofline_hbm["kernels"][name] = {"ms": round(ms_k, 3), "algorithmic_bytes": nbytes, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
         # PMC traffic is measured by separate rocprofv3 --pmc passes (tools/gpu_round.sh) and committed under profiles/ with the
         # hash of the kernel sources it was taken on; a file that does not match the sources of THIS build is not quoted.
-        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_hbm_{args.workload}.json")
+        pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_hbm_{args.workload}.json")
         if os.path.exists(pmc_path) and world == 1 and args.fma_policy == 0:
             pj = json.load(open(pmc_path))
             if pj.get("source_hash") == kernel_source_hash():
                 pmc = pj["kernels"]
                 if kname in pmc and "hbm_bytes_per_launch" in pmc[kname]:
                     roofline["traffic"] = pmc[kname]["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = f"profiles/r02_pmc_hbm_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, kernel sources {pj['source_hash']})"
+                    roofline["traffic_source"] = f"profiles/r03_pmc_hbm_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, kernel sources {pj['source_hash']})"
                 if kname in pmc and "valu_inst_per_cycle_simd" in pmc[kname]:
                     # same file, same kernel sources: SQ counters of the dominant kernel.  A wave64 binary32 VALU instruction issues at
                     # one per 2 cycles per SIMD (what the 157.3 TFLOP/s peak is made of: 64 lanes x 2 flop / 2 cycles x 1024 SIMDs x 2.4 GHz)
                     ipc = pmc[kname]["valu_inst_per_cycle_simd"]
                     roofline["valu_issue"] = {"inst_per_cycle_simd": round(ipc, 4), "peak": 0.5, "frac": round(ipc / 0.5, 4),
                                               "lanes_enabled": round(pmc[kname]["lanes_enabled"], 4),
-                                              "source": f"profiles/r02_pmc_hbm_{args.workload}.json (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
+                                              "source": f"profiles/r03_pmc_hbm_{args.workload}.json (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
                 roofline_hbm["pmc_traffic"] = {k: {"hbm_bytes": v["hbm_bytes"], "GBps": round(v.get("hbm_GBps", 0.0), 1)} for k, v in pmc.items()}
+                # k_shade_finish has no closed-form algorithmic byte count (its records exist per light-receiving hit): it is rated on
+                # the MEASURED traffic of the same kernel sources (PMC pass) over the live HIP-event time of this run
+                fin = next((v for k, v in pmc.items() if "k_shade_finish" in k), None)
+                if fin and st["ms_finish"] > 0:
+                    ach = fin["hbm_bytes"] / (st["ms_finish"] * 1e-3) / 1e9
+                    roofline_hbm["kernels"]["k_shade_finish (PMC-measured HBM bytes)"] = {"ms": round(st["ms_finish"], 3), "hbm_bytes": fin["hbm_bytes"], "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
             else:
-                roofline["traffic_note"] = f"profiles/r02_pmc_hbm_{args.workload}.json was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"
+                roofline["traffic_note"] = f"profiles/r03_pmc_hbm_{args.workload}.json was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"
         kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_shadow", "ms_finish", "ms_compact", "ms_resolve", "ms_total")}
     else:
         kernel_ms = None

@@ -97,7 +97,8 @@ struct Tables {
     void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scramble, const DTile* tiles, const uint32_t* pgrp_tile, \
                        Pool pool, uint32_t* q, uint32_t n_pool, DCtl* ctl);                         \
     void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t max_entries, Pool pool, \
-                       uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun); \
+                       uint8_t* ent_obj, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun); \
+    void launch_group_hist(hipStream_t s, uint32_t nclass, const uint8_t* ent_obj, uint32_t max_entries, const DCtl* ctl, uint8_t* grp_cnt); \
     void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt, \
                           const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total, \
                           uint32_t* tile_valid, uint32_t* tile_cls_cnt);                            \
@@ -132,6 +133,7 @@ struct KernelSet {
     decltype(&rayn_p0::launch_pack_tables) pack_tables;
     decltype(&rayn_p0::launch_raygen) raygen;
     decltype(&rayn_p0::launch_extend) extend;
+    decltype(&rayn_p0::launch_group_hist) group_hist;
     decltype(&rayn_p0::launch_scan_tile) scan_tile;
     decltype(&rayn_p0::launch_tile_prefix) tile_prefix;
     decltype(&rayn_p0::launch_bin_scatter) bin_scatter;
@@ -144,7 +146,7 @@ struct KernelSet {
     decltype(&rayn_p0::launch_probe_occluded) probe_occluded;
     decltype(&rayn_p0::launch_probe_detmath) probe_detmath;
 };
-#define RAYN_KERNEL_SET(NS) KernelSet{&NS::launch_pack_tables, &NS::launch_raygen, &NS::launch_extend, &NS::launch_scan_tile, &NS::launch_tile_prefix, &NS::launch_bin_scatter, &NS::launch_shade, &NS::launch_compact_scatter, &NS::launch_batch_setup, &NS::launch_resolve, &NS::launch_probe_dist, &NS::launch_probe_closest, &NS::launch_probe_occluded, &NS::launch_probe_detmath}
+#define RAYN_KERNEL_SET(NS) KernelSet{&NS::launch_pack_tables, &NS::launch_raygen, &NS::launch_extend, &NS::launch_group_hist, &NS::launch_scan_tile, &NS::launch_tile_prefix, &NS::launch_bin_scatter, &NS::launch_shade, &NS::launch_compact_scatter, &NS::launch_batch_setup, &NS::launch_resolve, &NS::launch_probe_dist, &NS::launch_probe_closest, &NS::launch_probe_occluded, &NS::launch_probe_detmath}
 inline KernelSet kernel_set(int fma_policy) {
     if (fma_policy) return RAYN_KERNEL_SET(rayn_p1);
     return RAYN_KERNEL_SET(rayn_p0);

@@ -21,7 +21,7 @@
 #include "kernels.h"
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "kernels.hip is written for gfx950 (MI355X): k_resolve_big / k_resolve_huge use 64 KB / 130 KB of the CU's 160 KB LDS"
+#error "kernels.hip is written for gfx950 (MI355X): k_resolve_blk<512, 8> / k_resolve_huge use 64 KB / 130 KB of the CU's 160 KB LDS"
 #endif
 
 namespace RAYN_KNS {
@@ -1330,10 +1330,13 @@ __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_resolve for 1024 < spp <= 4096 (config 5): the register-resident sort across the FOUR waves of a block, 16 keys per lane,
-// element e = tid * 16 + r.  Sub-steps inside a lane are register compare-exchanges, sub-steps inside a wave are shuffles, and
-// only the three sub-steps whose partner sits in another wave (jj >= 1024) go through LDS - the LDS version paid 78 x 32
-// dependent LDS round trips per sort at 4096 spp (12 % of a config-5 frame in r1).
+// k_resolve_blk for 512 < spp <= 4096 (configs 3 / 4 / 5): the register-resident sort across the 2 / 4 / 8 waves of a block, EIGHT
+// keys per lane, element e = tid * 8 + r.  Sub-steps inside a lane are register compare-exchanges, sub-steps inside a wave are
+// shuffles, and only the sub-steps whose partner sits in another wave (jj >= 512: 1 / 3 / 6 of the 55 / 66 / 78) go through LDS.
+// Eight keys per lane instead of r2's sixteen (one wave per pixel at 1024 spp, four at 4096): the sort is a chain of dependent
+// shuffles, i.e. latency-bound, and 16 u64 keys + 16 exchange registers cost 118-131 VGPRs - with 16 B of LDS per sample that
+// left 2.5 (1024 spp) / 2 (4096 spp) waves per SIMD.  Half the keys per lane = ~75 VGPRs, half the chain length per lane and
+// twice the waves per pixel: 5 / 4 waves per SIMD on the same LDS.
 // ------------------------------------------------------------------------------------------------
 template <typename K, uint32_t KPL, uint32_t NT = 256>
 RD void bitonic_sort_block4(K (&key)[KPL], K* exch /* [NT * KPL] */) {
@@ -1383,18 +1386,19 @@ RD void bitonic_sort_block4(K (&key)[KPL], K* exch /* [NT * KPL] */) {
     (void)lane;
 }
 
-__global__ void __launch_bounds__(256) k_resolve_big(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
-                                                      float* __restrict__ out_color, float* __restrict__ out_alpha,
-                                                      float* __restrict__ out_background, float* __restrict__ out_normal) {
-    constexpr uint32_t KPL = 16, n_sort = 256 * KPL; // 4096
-    // 64 KB: the sorted samples' (r, g) and (b, flag) for the serial-sum lanes; the sort's cross-wave exchange (32 KB of u64 keys)
+template <uint32_t NT, uint32_t KPL>
+__global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
+                                                     float* __restrict__ out_color, float* __restrict__ out_alpha,
+                                                     float* __restrict__ out_background, float* __restrict__ out_normal) {
+    constexpr uint32_t n_sort = NT * KPL; // 1024 (2 waves x 8 keys), 2048 (4 x 8) or 4096 (8 x 8)
+    // 16 B per sample: the sorted samples' (r, g) and (b, flag) for the serial-sum lanes; the sort's cross-wave exchange (u64 keys)
     // and the sortedness check use the same memory before the staging starts
     __shared__ __attribute__((aligned(16))) float2 rg[n_sort];
     __shared__ __attribute__((aligned(16))) float2 bf[n_sort];
-    __shared__ uint32_t s_cnt;
-    unsigned long long* exch64 = (unsigned long long*)rg; // [4096] u64 = 32 KB = rg
+    unsigned long long* exch64 = (unsigned long long*)rg; // [n_sort] u64 = rg
     uint32_t* exch32 = (uint32_t*)rg;
     float* nz = (float*)bf;
+    uint32_t* s_meta = (uint32_t*)bf; // [0] valid keys, [1] "some pair is out of order": only live between the key load and the sort (bf is staged later)
     constexpr unsigned long long NOKEY = ~0ull;
     const DScene& sc = *scp;
     const DTile tile = tiles[blockIdx.y];
@@ -1409,7 +1413,7 @@ __global__ void __launch_bounds__(256) k_resolve_big(const DScene* __restrict__ 
     uint32_t mine = 0;
 #pragma unroll
     for (uint32_t r = 0; r < KPL; r++) { // sample-major: register r of thread t = sample r * 256 + t (coalesced)
-        const uint32_t i = r * 256 + tid;
+        const uint32_t i = r * NT + tid;
         unsigned long long k = NOKEY;
         if (i < spp) {
             const uint32_t info = pool.term_info[P0 + i];
@@ -1420,20 +1424,22 @@ __global__ void __launch_bounds__(256) k_resolve_big(const DScene* __restrict__ 
         mine += k != NOKEY;
         exch64[i] = k;
     }
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) { s_meta[0] = 0; s_meta[1] = 0; }
     __syncthreads();
     bool ok = true;
 #pragma unroll
-    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * 256 + tid; ok = ok && (i + 1 >= n_sort || !(key[r] > exch64[i + 1])); }
-    if (mine) atomicAdd(&s_cnt, mine);
-    const bool sorted = __syncthreads_or(!ok) == 0; // also orders the LDS reads above before the exchange buffer is reused
-    const uint32_t cnt = s_cnt;
-    if (!sorted) bitonic_sort_block4<unsigned long long, KPL>(key, exch64); // now element tid * KPL + r
+    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * NT + tid; ok = ok && (i + 1 >= n_sort || !(key[r] > exch64[i + 1])); }
+    if (mine) atomicAdd(&s_meta[0], mine);
+    if (!ok) s_meta[1] = 1;
+    __syncthreads(); // also orders the LDS reads above before the exchange buffer is reused
+    const uint32_t cnt = s_meta[0];
+    const bool sorted = s_meta[1] == 0;
+    if (!sorted) bitonic_sort_block4<unsigned long long, KPL, NT>(key, exch64); // now element tid * KPL + r
     __syncthreads();
 #pragma unroll
     for (uint32_t r = 0; r < KPL; r++) {
         if (key[r] != NOKEY) {
-            const uint32_t e = sorted ? r * 256 + tid : tid * KPL + r, lo = (uint32_t)key[r];
+            const uint32_t e = sorted ? r * NT + tid : tid * KPL + r, lo = (uint32_t)key[r];
             const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
             rg[e] = make_float2(c.x, c.y);
             bf[e] = make_float2(c.z, __uint_as_float((lo >> 12) & 1u));
@@ -1469,27 +1475,29 @@ __global__ void __launch_bounds__(256) k_resolve_big(const DScene* __restrict__ 
     mine = 0;
 #pragma unroll
     for (uint32_t r = 0; r < KPL; r++) {
-        const uint32_t i = r * 256 + tid;
+        const uint32_t i = r * NT + tid;
         uint32_t k = INVALID;
         if (i < spp) { const uint32_t ob = __float_as_uint(pool.aov[P0 + i].w); if (ob != OBJ_NONE) k = (ob << 16) | i; }
         k32[r] = k;
         mine += k != INVALID;
         exch32[i] = k;
     }
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) { s_meta[0] = 0; s_meta[1] = 0; }
     __syncthreads();
     ok = true;
 #pragma unroll
-    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * 256 + tid; ok = ok && (i + 1 >= n_sort || !(k32[r] > exch32[i + 1])); }
-    if (mine) atomicAdd(&s_cnt, mine);
-    const bool sorted0 = __syncthreads_or(!ok) == 0;
-    const uint32_t cnt0 = s_cnt;
-    if (!sorted0) bitonic_sort_block4<uint32_t, KPL>(k32, exch32);
+    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * NT + tid; ok = ok && (i + 1 >= n_sort || !(k32[r] > exch32[i + 1])); }
+    if (mine) atomicAdd(&s_meta[0], mine);
+    if (!ok) s_meta[1] = 1;
+    __syncthreads();
+    const uint32_t cnt0 = s_meta[0];
+    const bool sorted0 = s_meta[1] == 0;
+    if (!sorted0) bitonic_sort_block4<uint32_t, KPL, NT>(k32, exch32);
     __syncthreads();
 #pragma unroll
     for (uint32_t r = 0; r < KPL; r++)
         if (k32[r] != INVALID) {
-            const uint32_t e = sorted0 ? r * 256 + tid : tid * KPL + r;
+            const uint32_t e = sorted0 ? r * NT + tid : tid * KPL + r;
             const float4 a = pool.aov[P0 + (k32[r] & 0xFFFFu)];
             rg[e] = make_float2(a.x, a.y);
             nz[e] = a.z;
@@ -1783,13 +1791,15 @@ void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scr
     hipLaunchKernelGGL(k_raygen, grid_for(n_pool, 256), dim3(256), 0, s, sc, tab, scramble, tiles, pgrp_tile, pool, q, n_pool, ctl);
 }
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t max_entries, Pool pool,
-                   uint8_t* ent_obj, uint8_t* grp_cnt, uint32_t nclass, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun) {
+                   uint8_t* ent_obj, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun) {
     const dim3 grid = stride_grid(max_entries, 256, tun.persistent_blocks);
     if (single_sdf >= 0 && tun.fast_path) {
         if (count) hipLaunchKernelGGL(k_extend1<true>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
         else hipLaunchKernelGGL(k_extend1<false>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
     } else if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
     else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
+}
+void launch_group_hist(hipStream_t s, uint32_t nclass, const uint8_t* ent_obj, uint32_t max_entries, const DCtl* ctl, uint8_t* grp_cnt) {
     hipLaunchKernelGGL(k_group_hist, stride_grid(max_entries, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, ent_obj, ctl, grp_cnt);
 }
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
@@ -1852,11 +1862,12 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
         else if (spp <= 128) hipLaunchKernelGGL(k_resolve_reg<2>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         else if (spp <= 256) hipLaunchKernelGGL(k_resolve_reg<4>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         else if (spp <= 512) hipLaunchKernelGGL(k_resolve_reg<8>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
-        else hipLaunchKernelGGL(k_resolve_reg<16>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        else hipLaunchKernelGGL((k_resolve_blk<128, 8>), grid, dim3(128), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal); // two waves per pixel
         return;
     }
-    if (spp <= 4096) { // four waves per pixel, 16 keys per lane (config 5)
-        hipLaunchKernelGGL(k_resolve_big, grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+    if (spp <= 4096) { // four / eight waves per pixel, 8 keys per lane (config 5: 4096 spp)
+        if (spp <= 2048) hipLaunchKernelGGL((k_resolve_blk<256, 8>), grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        else hipLaunchKernelGGL((k_resolve_blk<512, 8>), grid, dim3(512), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         return;
     }
     // 4096 < spp <= 16384 (the host rejects more): sixteen waves per pixel, 128 KB of dynamic LDS

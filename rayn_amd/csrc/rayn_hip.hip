@@ -433,10 +433,11 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
                 WCHK(hipStreamSynchronize(stream));
                 if (w->h_totals[1] == 0) break;
             }
-            { Timed t(w, prof, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, max_entries, pool, ent_obj, grp_cnt, hs.n_hitables, F.single_sdf, d_ctl, w->d_evals, ctx->tun); }
+            { Timed t(w, prof, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, max_entries, pool, ent_obj, F.single_sdf, d_ctl, w->d_evals, ctx->tun); }
             w->stats.launches_extend++;
             {
                 Timed t(w, prof, PC_BIN);
+                K.group_hist(stream, hs.n_hitables, ent_obj, max_entries, d_ctl, grp_cnt); // timed with the bin stage it feeds (r1 / r2 timed it with the extend kernel)
                 K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt);
                 K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0, hs.n_hitables, 4, tile_cls_cnt, tile_cls_base, (uint32_t)(BCAP / 64));
                 K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, max_entries, bq, nt, tile_cls_cnt, tile_total, tile_cls_base, d_ctl);

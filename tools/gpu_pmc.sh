@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-roofline --cpu-seconds 0 "$@" > $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-roofline --no-cold --cpu-seconds 0 "$@" > $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG.log 2>&1)
 tail -3 gpurun_out/pmc_$TAG.log
 F=$(find $OUT -name "*counter_collection.csv" | head -1)
 python - "$F" > gpurun_out/pmc_$TAG.csv <<'PY'

@@ -1,8 +1,9 @@
 # Round evidence pass (one gpurun call): parity tests + fuzz, then per workload (c3 = bench default, c2):
 #   rocprofv3 kernel stats (1 worker and 2 workers), PMC FETCH_SIZE / WRITE_SIZE passes, bench JSON lines.
-# usage: bash tools/gpu_round.sh <tag> [workloads...]      outputs under gpurun_out/ and profiles/r02_*
+# usage: bash tools/gpu_round.sh <tag> [workloads...]      outputs under gpurun_out/ and profiles/${R}_*
 set -x
 TAG=${1:-v1}; shift
+R=${ROUND:-r03}
 WLS=${@:-c3 c2}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -11,26 +12,28 @@ timeout 900 python tools/fuzz_parity.py 150 5000 2>&1 | tail -4
 for WL in $WLS; do
   # per-kernel evidence is collected single-worker (the two-worker pipeline overlaps kernels, which inflates their durations)
   export RAYN_HIP_WORKERS=1
+  export RAYN_HIP_COLD_BYTES=0   # the profiled frame is the only frame of its process: full-size batches at once (bench.py --no-cold)
   bash tools/gpu_profile.sh $WL --workload $WL > /dev/null 2>&1
   bash tools/gpu_pmc.sh fetch_$WL "FETCH_SIZE" --workload $WL > /dev/null 2>&1
   bash tools/gpu_pmc.sh write_$WL "WRITE_SIZE" --workload $WL > /dev/null 2>&1
   # VALU issue counters of the same single-worker frame (two passes of four counters)
   bash tools/gpu_pmc.sh sq1_$WL "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES" --workload $WL > /dev/null 2>&1
   bash tools/gpu_pmc.sh sq2_$WL "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_SALU" --workload $WL > /dev/null 2>&1
-  python tools/pmc_join.py gpurun_out/pmc_sq1_$WL.csv gpurun_out/pmc_sq2_$WL.csv > gpurun_out/r02_${WL}_${TAG}_pmc_sq.csv
+  python tools/pmc_join.py gpurun_out/pmc_sq1_$WL.csv gpurun_out/pmc_sq2_$WL.csv > gpurun_out/${R}_${WL}_${TAG}_pmc_sq.csv
   unset RAYN_HIP_WORKERS
   bash tools/gpu_profile.sh ${WL}_2workers --workload $WL > /dev/null 2>&1
-  python tools/pmc_to_json.py $WL profiles/r02_pmc_hbm_$WL.json gpurun_out/prof_${WL}_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_pmc_sq.csv > gpurun_out/pmc_hbm_$WL.txt
-  cp profiles/r02_pmc_hbm_$WL.json gpurun_out/
-  cp gpurun_out/prof_${WL}_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_kernel_stats_1worker.csv
-  cp gpurun_out/prof_${WL}_2workers_kernel_stats.csv gpurun_out/r02_${WL}_${TAG}_kernel_stats_2workers.csv
-  cp gpurun_out/pmc_fetch_$WL.csv gpurun_out/r02_${WL}_${TAG}_pmc_fetch_size.csv
-  cp gpurun_out/pmc_write_$WL.csv gpurun_out/r02_${WL}_${TAG}_pmc_write_size.csv
-  timeout 1200 python bench.py --workload $WL 2>&1 | tail -1 > gpurun_out/r02_bench_${WL}_$TAG.json
-  timeout 900 python bench.py --workload $WL --fma-policy 1 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/r02_bench_${WL}_${TAG}_fma1.json
+  unset RAYN_HIP_COLD_BYTES
+  python tools/pmc_to_json.py $WL profiles/${R}_pmc_hbm_$WL.json gpurun_out/prof_${WL}_kernel_stats.csv gpurun_out/${R}_${WL}_${TAG}_pmc_sq.csv > gpurun_out/pmc_hbm_$WL.txt
+  cp profiles/${R}_pmc_hbm_$WL.json gpurun_out/
+  cp gpurun_out/prof_${WL}_kernel_stats.csv gpurun_out/${R}_${WL}_${TAG}_kernel_stats_1worker.csv
+  cp gpurun_out/prof_${WL}_2workers_kernel_stats.csv gpurun_out/${R}_${WL}_${TAG}_kernel_stats_2workers.csv
+  cp gpurun_out/pmc_fetch_$WL.csv gpurun_out/${R}_${WL}_${TAG}_pmc_fetch_size.csv
+  cp gpurun_out/pmc_write_$WL.csv gpurun_out/${R}_${WL}_${TAG}_pmc_write_size.csv
+  timeout 1200 python bench.py --workload $WL 2>&1 | tail -1 > gpurun_out/${R}_bench_${WL}_$TAG.json
+  timeout 900 python bench.py --workload $WL --fma-policy 1 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/${R}_bench_${WL}_${TAG}_fma1.json
   python -c "
 import json
-for f in ('gpurun_out/r02_bench_${WL}_$TAG.json','gpurun_out/r02_bench_${WL}_${TAG}_fma1.json'):
+for f in ('gpurun_out/${R}_bench_${WL}_$TAG.json','gpurun_out/${R}_bench_${WL}_${TAG}_fma1.json'):
     j=json.load(open(f)); print('VALUE', j['value'], j['ms_per_step']); print(j['kernel_ms']); print({k:j['roofline'][k] for k in ('kernel','achieved','frac','traffic')}); print(j['cpu_baseline'])
     for k, v in j['roofline_hbm']['kernels'].items(): print('   ', k[:40], v['ms'], v['frac'])"
   cat gpurun_out/pmc_hbm_$WL.txt
