@@ -276,9 +276,9 @@ int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
 /* First frame of a context (no reference counterpart; the reference renders ONE frame per process, src/main.rs:47-96).  Device
  * memory that a process released is wiped by the driver before another process can use it; a fresh process that takes a
  * full-size arena (up to 60 % of the HBM) right after another one exited runs its first frame up to 3.5 s longer (measured,
- * profiles/r03_cold_start.txt).  The FIRST frame a context renders therefore sizes its batches for an arena of at most `bytes`
- * per worker (default 44 GB: 2^26-path batches of the volume path, 2^27 without - a quarter of the full size, 2.5 % slower); from
- * its second frame on a context uses full-size batches.  The
+ * profiles/r03_cold_start.txt).  The FIRST frame a context renders therefore sizes its batches for arenas of at most `bytes`
+ * in total (default 44 GB: one worker with 2^26-path batches of the volume path, 2^27 without - a quarter of the full size,
+ * 2.5 % slower); from its second frame on a context uses full-size batches.  The
  * result is bit-identical (batching never changes a pixel: packets are per tile).  0 = full size from the first frame; also
  * RAYN_HIP_COLD_BYTES at context creation. */
 int rayn_hip_set_cold_bytes(rayn_ctx* ctx, uint64_t bytes);

@@ -79,7 +79,7 @@ struct rayn_ctx {
     bool profiling = false, counting = false;
     size_t batch_paths = (size_t)1 << 28;   // per worker; also limited by the HBM budget and the 32-bit job refs (render_device)
     size_t two_worker_min_paths = (size_t)1 << 22;
-    size_t cold_bytes = (size_t)44 << 30;   // arena size per worker of a context's FIRST frame (render_device); 0 = full size at once
+    size_t cold_bytes = (size_t)44 << 30;   // arena bytes (all workers together) of a context's FIRST frame (render_device); 0 = full size at once
     uint64_t frames_rendered = 0;
     float* host_stage = nullptr; size_t host_stage_cap = 0; // rayn_hip_render_frame: device copies of the caller's tables + film (grow-only)
     int n_workers = 2;
@@ -582,19 +582,20 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         for (int c = std::max(max_w, 1); c >= 1; c--) {
             // 32-bit [sample][slot] refs: NS * (binned slots of a batch) must stay below 2^32 (5 % slack for bin padding and tile tails)
             const size_t index_cap = (size_t)(0.95 * 4294967296.0 / (double)F.NS);
-            // FIRST FRAME of a context: arenas of at most cold_bytes per worker (44 GB: 2^26-path batches with the volume path's
-            // 667 B per path, 2^27 without).  The reference renders ONE frame per process
-            // (src/main.rs:47-96) - a render farm runs such processes back to back - and device memory that a process released is
-            // wiped by the driver before the next one can use it: measured (tools/cold_frame.py, profiles/r03_cold_start.txt), a
+            // FIRST FRAME of a context: arenas of at most cold_bytes for ALL workers together (44 GB: 2^26-path batches with the
+            // volume path's 667 B per path, 2^27 without).  The reference renders ONE frame per process (src/main.rs:47-96) - a
+            // render farm runs such processes back to back - and device memory that a process released is wiped by the driver
+            // before the next one can use it, at ~20-40 ms per GB: measured (tools/cold_frame.py, profiles/r03_cold_start.txt), a
             // fresh process whose first frame takes a 175 GB arena runs that frame 3.5 s longer when it starts right after a
-            // process of the same size (+1.0-1.2 s at 87-104 GB, +0.0 s after a 6 s pause; obtaining the arena on a side thread
-            // does not hide it - the running kernels stall too).  A quarter of the memory costs 2.5 % of steady-state speed; a
-            // context that renders a second frame grows to the full size then.
-            const size_t first = (ctx->frames_rendered == 0 && ctx->cold_bytes) ? ctx->cold_bytes / per_path : ~(size_t)0;
+            // process of the same size (+0.0 s after a 6 s pause; obtaining the arena on a side thread does not hide it - the
+            // running kernels stall too).  A quarter of the memory costs 2.5 % of steady-state speed; a context that renders a
+            // second frame grows to the full size then.
+            const size_t first = (ctx->frames_rendered == 0 && ctx->cold_bytes) ? ctx->cold_bytes / per_path / (size_t)c : ~(size_t)0;
             const size_t cap = std::max<size_t>(4096, std::min(first, std::min(std::min(ctx->batch_paths, index_cap), budget_paths / (size_t)c)));
             // a further worker must not cost batch size: with c workers each still gets >= 3/4 of the batch one worker would get
             // (config 3, 651 B per path: one worker with 2^28-path batches beats two with 2^27; config 2, 331 B: both fit)
-            const size_t solo = std::max<size_t>(4096, std::min(first, std::min(std::min(ctx->batch_paths, index_cap), budget_paths)));
+            const size_t first1 = first == ~(size_t)0 ? first : first * (size_t)c; // what ONE worker would get of the first-frame budget
+            const size_t solo = std::max<size_t>(4096, std::min(first1, std::min(std::min(ctx->batch_paths, index_cap), budget_paths)));
             if (c == 1 || (owned_paths >= ctx->two_worker_min_paths && owned_paths >= (size_t)c * cap && 4 * cap >= 3 * solo) ||
                 (ctx->two_worker_min_paths == 0)) { nw = c; F.batch_paths = cap; break; }
         }

@@ -46,3 +46,8 @@ timeout 600 python tools/share_profile.py 5 64 c5 2>&1 | tail -1 | sed 's/^/c5 1
 timeout 600 python tools/share_profile.py 0 1 bulb 2>&1 | tail -1 | sed 's/^/bulb: /'
 timeout 600 python tools/host_rate.py c3 2>&1 | tail -1
 timeout 600 python tools/host_rate.py c2 2>&1 | tail -1
+timeout 600 python bench.py --workload c4 --steps 1 --warmup 1 --no-roofline --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/${R}_bench_c4_$TAG.json; cat gpurun_out/${R}_bench_c4_$TAG.json | cut -c1-200
+timeout 900 python bench.py --workload c5 --steps 1 --warmup 0 --no-roofline --no-cold --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/${R}_bench_c5_$TAG.json; cat gpurun_out/${R}_bench_c5_$TAG.json | cut -c1-200
+# the reference's own usage: one frame per process, back to back (tools/cold_frame.py)
+sleep 6
+for WL in c3 c3 c2 c2; do timeout 300 python tools/cold_frame.py $WL -1 0 2>&1 | tail -1; done
