@@ -56,3 +56,29 @@ def test_bench_rccl_code_path_world1():
     assert out["n_gpus"] == 1 and out["film_check"] is True
     assert "RCCL gather" in out["config"]["parallelism"] and "TEST MODE" not in out["config"]["parallelism"]
     assert out["segments_per_step"] > out["config"]["paths_per_step"]  # summed over ranks by all-reduce: every path has >= 1 segment
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_n1():
+    """The default (N = 1) launch on a small workload: ONE JSON line with the driver's keys, a live `roofline` (dominant march kernel,
+    HIP-event timed), `roofline_hbm`, `cpu_baseline` (kind "port", bounded sample), `cold_ms` (fresh context -> first frame through
+    the host-buffer entry) and the build variant "product"."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "small", "--cpu-seconds", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "cold_ms"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f32" and out["vs_baseline"] is None
+    assert out["value"] > 0 and abs(out["value"] - out["config"]["paths_per_step"] / out["ms_per_step"] / 1e3) < 1e-2 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "k_extend1" in rf["kernel"] or "k_shadow1" in rf["kernel"] or "k_shade_setup" in rf["kernel"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "tiles" in cb["sample"]
+    assert out["cold_ms"] > 0 and out["config"]["build_variant"] == "product"
+    assert all(0 <= v["frac"] < 1.5 for v in out["roofline_hbm"]["kernels"].values())
