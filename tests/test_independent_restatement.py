@@ -223,3 +223,69 @@ def test_occluded_second_restatement(oracle):
         vis = (vis * occ).astype(f32)
     assert 0.05 < ref.mean() < 0.95  # both outcomes are exercised
     assert np.array_equal(vis.view(np.uint32), ref.view(np.uint32))
+
+
+# ---- the whole path: ray-gen -> closest hit -> bins / packets -> shading info -> NEE (surface + volume) -> scatter -> roulette ->
+# ---- film add order -> normalise, restated a second time in tests/restatement_np.py ---------------------------------------------------
+@pytest.mark.parametrize("name,W,H,samples,bounces,kw", [
+    ("s2", 32, 16, 2, 4, {}),                       # MandelBox + homogeneous volume, two 16x16 tiles, roulette depth reached
+    ("s1", 24, 20, 2, 5, {"tile_size": (8, 8)}),   # volumes off, 3 x 3 tiles of 8 x 8 incl. clipped ones ((20 + 20 % 8) / 8 = 3 rows)
+    ("s0", 20, 16, 2, 3, {"tile_size": (16, 16)}),  # BASELINE config 1's scene; 20 columns at tile 16: the reference's grid leaves 4 uncovered
+])
+def test_whole_film_second_restatement(oracle, name, W, H, samples, bounces, kw):
+    """tests/restatement_np.py renders the film with code written from the Rust text alone (numpy binary32; transcendentals = binary64
+    numpy functions rounded once): every float of Color / Alpha / Background / WorldNormal and the path / segment counts must equal
+    the C++ oracle's.  This pins the oracle's transcription of packet grouping (F7), per-bounce sample indexing, the NEE and BSDF
+    operand orders and the film add order against a second reading of the reference; it cannot pin the third-party semantics
+    both restatements assume (A1-A9)."""
+    import restatement_np as RN
+    wd, p = case(name, W, H, samples, bounces, **kw)
+    tabs = oracle.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W, H)
+    ref, ctr = oracle.render(wd, p, tabs)
+    got, c2 = RN.render(wd, p, tabs)
+    assert c2["paths"] == ctr.paths and c2["segments"] == ctr.segments
+    assert ctr.segments > ctr.paths  # paths do bounce
+    for k in ("color", "alpha", "background", "normal"):
+        a = got[k].reshape(-1).view(np.uint32)
+        b = np.ascontiguousarray(ref[k], np.float32).reshape(-1).view(np.uint32)
+        assert np.array_equal(a, b), (k, int((a != b).sum()))
+    assert float(ref["color"].max()) > 0 and float(ref["alpha"].max()) > 0
+
+
+@pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "anim_spheres", "lambertian", "no_lights", "spheres_only",
+                                  "two_sdfs", "lambert_sdf_sphere"])
+def test_closed_set_second_restatement(oracle, kind):
+    """The rest of the reference's closed set through the second restatement: ThinLens / Orthographic cameras (src/camera.rs:120-285),
+    closure-sequenced camera parameters and sphere centres with their lane-0-time semantics (src/animation.rs:62-68), Lambertian,
+    scenes without lights / without an SDF / with two SDFs - same scenes as tests/test_gpu_parity.py::test_closed_set_parity renders on
+    the GPU, so kernels, oracle and this restatement all produce the same bits."""
+    import restatement_np as RN
+    from rayn_amd import params as P
+    from test_gpu_parity import _custom_world
+    W, H, samples, bounces = 16, 16, 1, 4
+    wd = _custom_world(kind, (W, H))
+    p = P.frame_params(W, H, samples, bounces, time_range=(0.1, 0.3))
+    tabs = oracle.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W, H)
+    ref, ctr = oracle.render(wd, p, tabs)
+    got, c2 = RN.render(wd, p, tabs)
+    assert c2["paths"] == ctr.paths and c2["segments"] == ctr.segments
+    for k in ("color", "alpha", "background", "normal"):
+        a = got[k].reshape(-1).view(np.uint32)
+        b = np.ascontiguousarray(ref[k], np.float32).reshape(-1).view(np.uint32)
+        assert np.array_equal(a, b), (k, int((a != b).sum()))
+
+
+@pytest.mark.parametrize("kind,radius,params", [(0, 1.5, (0.0, 0.0)), (1, 0.5, (0.0, 0.0)), (2, 2.0, (1.0 / 3.0, 1.0 / 3.0)), (2, 2.0, (1.0, 0.0)), (3, 3.0, (3.0, 0.0))])
+def test_filter_importance_sampler_second_restatement(oracle, kind, radius, params):
+    """FilterImportanceSampler::new + CDF over BlackmanHarris / Box / MitchellNetravali / LanczosSinc restated a second time (scalar
+    binary32, cos / sin from binary64): the 512-entry inverse CDF equals the oracle's and the product's host builder bit for bit."""
+    import rayn_amd
+    import restatement_np as RN
+    import ctypes as C
+    from rayn_amd._lib import lib
+    mine = RN.fis_table(kind, radius, *params)
+    ref = oracle.build_tables(4, 0, 2, 1, 4, 4, filter_kind=kind, filter_radius=radius, filter_params=params)[3]
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), int((mine.view(np.uint32) != ref.view(np.uint32)).sum())
+    prod = np.zeros(512, np.float32)
+    assert lib().rayn_build_fis_table_ex(kind, C.c_float(radius), C.c_float(params[0]), C.c_float(params[1]), prod.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert np.array_equal(mine.view(np.uint32), prod.view(np.uint32))
