@@ -139,12 +139,15 @@ def mat_vec(m, v):  # Wat3 * Wec3 = c0 * x + c1 * y + c2 * z (A4)
 
 
 # ---- MandelBox (src/sdf.rs:104-188) --------------------------------------------------------------------------------------
-def mandelbox_dist(p0, h):
+def mandelbox_dist(p0, h, t0=None):
+    """t0 (lane 0's time of the calling packet) only matters for the EXTENSION `scale = |t| scale + scale_vel * t` (include/rayn_hip.h)"""
     if h.sdf_kind == 0:  # sdfu::Sphere (A5): |p| - r
         with np.errstate(all="ignore"):
             return (mag(p0) - f32(h.sdf_radius)).astype(f32)
-    assert h.sdf_kind == 1 and not h.animated and h.scale_vel == 0.0 and (h.center.x, h.center.y, h.center.z) == (0.0, 0.0, 0.0), "TracedSDF transform / scale closures are extensions beyond the reference: not restated here"
+    assert h.sdf_kind == 1, "the Mandelbulb extension is not restated here"
     l, mrs, frs, s = f32(h.box_side), f32(f32(h.min_radius) * f32(h.min_radius)), f32(f32(h.fixed_radius) * f32(h.fixed_radius)), f32(h.scale)
+    if h.scale_vel != 0.0:
+        s = (f32(h.scale) + (f32(h.scale_vel) * t0).astype(f32)).astype(f32)
     p = [c.copy() for c in p0]
     dr = np.ones_like(p0[0])
     with np.errstate(all="ignore"):
@@ -201,13 +204,14 @@ def sphere_occluded(h, a, b, t0):  # src/sphere.rs:24-46: 0 occluded, 1 not
     return np.where(valid, f32(0.0), f32(1.0)).astype(f32)
 
 
-def sdf_hit(h, o, d, t_max, thr_at, ds_, max_marches):  # src/sdf.rs:59-83
-    t = mandelbox_dist(o, h)
+def sdf_hit(h, o, d, t_max, thr_at, ds_, max_marches, t0):  # src/sdf.rs:59-83 (+ EXTENSION: the SDF's frame is translated by its origin)
+    o = vsub(o, sphere_center(h, t0))
+    t = mandelbox_dist(o, h, t0)
     nan = np.isnan(t)
     done = np.zeros(len(t), bool)
     for _ in range(max_marches):
         pt = [mul_add(d[c], t, o[c]) for c in range(3)]
-        di = mandelbox_dist(pt, h)
+        di = mandelbox_dist(pt, h, t0)
         hit = np.abs(di) < smax(np.full_like(t, f32(0.00005) * f32(ds_)), (f32(f32(0.05) * f32(ds_)) * thr_at(t)).astype(f32))
         stop = hit | nan | (t > t_max)
         t = np.where(stop | done, t, (t + di).astype(f32))  # a stopped lane is idempotent in the packet loop
@@ -217,11 +221,13 @@ def sdf_hit(h, o, d, t_max, thr_at, ds_, max_marches):  # src/sdf.rs:59-83
     return t
 
 
-def sdf_occluded(h, a, b, ds_, max_vis):  # src/sdf.rs:25-57
+def sdf_occluded(h, a, b, ds_, max_vis, t0):  # src/sdf.rs:25-57 (+ EXTENSION: both ends in the SDF's frame)
+    org = sphere_center(h, t0)
+    a, b = vsub(a, org), vsub(b, org)
     dirv = vsub(b, a)
     max_dist = mag(dirv)
     dirv = vdiv(dirv, max_dist)
-    dist = mandelbox_dist(a, h)
+    dist = mandelbox_dist(a, h, t0)
     nan = np.isnan(dist)
     gt_nan = (dist > max_dist) | nan
     hit = dist < f32(0.0001)
@@ -232,7 +238,7 @@ def sdf_occluded(h, a, b, ds_, max_vis):  # src/sdf.rs:25-57
         if (gt_nan | frozen).all():
             break
         pt = [mul_add(dirv[c], t, a[c]) for c in range(3)]
-        di = mandelbox_dist(pt, h)
+        di = mandelbox_dist(pt, h, t0)
         hit_new = np.abs(di) < smax(np.full_like(t, f32(0.0001) * f32(ds_)), (f32(f32(0.00001) * f32(ds_)) * t).astype(f32))
         hit = np.where(frozen | gt_nan, hit, hit_new)
         stop = hit | gt_nan
@@ -248,7 +254,7 @@ def test_occluded(wd, p, a, b, t0):  # HitableStore::test_occluded, src/hitable.
     with np.errstate(all="ignore"):
         for i in range(wd.n_hitables):
             h = wd.hitables[i]
-            occ = sphere_occluded(h, a, b, t0) if h.kind == 0 else sdf_occluded(h, a, b, p.sdf_detail_scale, int(p.max_vis_marches))
+            occ = sphere_occluded(h, a, b, t0) if h.kind == 0 else sdf_occluded(h, a, b, p.sdf_detail_scale, int(p.max_vis_marches), t0)
             vis = (vis * occ).astype(f32)
     return vis
 
@@ -504,7 +510,7 @@ def render(wd, p, tabs):
                 with np.errstate(all="ignore"):
                     for i in range(wd.n_hitables):
                         h = wd.hitables[i]
-                        t = sphere_hit(h, o, d, closest, rays["time"][(v // 4) * 4]) if h.kind == 0 else sdf_hit(h, o, d, closest, thr_at, p.sdf_detail_scale, int(p.max_marches))
+                        t = sphere_hit(h, o, d, closest, rays["time"][(v // 4) * 4]) if h.kind == 0 else sdf_hit(h, o, d, closest, thr_at, p.sdf_detail_scale, int(p.max_marches), rays["time"][(v // 4) * 4])
                         win = t < closest
                         closest = np.where(win, t, closest).astype(f32)
                         ids = np.where(win, i, ids)
@@ -546,10 +552,12 @@ def render(wd, p, tabs):
                             ob = np.zeros(len(sel), f32)
                         else:  # src/sdf.rs:85-101 + sdfu normals_fast (A5)
                             ob = smax(np.full(len(sel), f32(0.0001), f32), (f32(p.sdf_detail_scale) * thr_at(ht[sel])).astype(f32))
+                            tp = R["time"][(sel // 4) * 4]
+                            ps = vsub(ps, sphere_center(h, tp))  # EXTENSION: the normal is estimated in the SDF's frame (zero origin in the reference)
                             gsum = None
                             for kx, ky, kz in ((1, -1, -1), (-1, -1, 1), (-1, 1, -1), (1, 1, 1)):
                                 kv = [np.full(len(sel), f32(kx), f32), np.full(len(sel), f32(ky), f32), np.full(len(sel), f32(kz), f32)]
-                                term = vscale(kv, mandelbox_dist(vadd(ps, vscale(kv, ob)), h))
+                                term = vscale(kv, mandelbox_dist(vadd(ps, vscale(kv, ob)), h, tp))
                                 gsum = term if gsum is None else vadd(gsum, term)
                             nn = normalized(gsum)
                         for c in range(3):

@@ -253,12 +253,14 @@ def test_whole_film_second_restatement(oracle, name, W, H, samples, bounces, kw)
 
 
 @pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "anim_spheres", "lambertian", "no_lights", "spheres_only",
-                                  "two_sdfs", "lambert_sdf_sphere"])
+                                  "two_sdfs", "lambert_sdf_sphere", "offset_sdf", "moving_sdf", "moving_two_sdfs", "morphing_box", "morphing_two_sdfs"])
 def test_closed_set_second_restatement(oracle, kind):
     """The rest of the reference's closed set through the second restatement: ThinLens / Orthographic cameras (src/camera.rs:120-285),
     closure-sequenced camera parameters and sphere centres with their lane-0-time semantics (src/animation.rs:62-68), Lambertian,
     scenes without lights / without an SDF / with two SDFs - same scenes as tests/test_gpu_parity.py::test_closed_set_parity renders on
-    the GPU, so kernels, oracle and this restatement all produce the same bits."""
+    the GPU, so kernels, oracle and this restatement all produce the same bits.  The last five are this repo's EXTENSIONS (a TracedSDF with a
+    constant / closure origin, the MandelBox scale as a closure: include/rayn_hip.h) - there the second restatement follows the header's
+    description, not the reference."""
     import restatement_np as RN
     from rayn_amd import params as P
     from test_gpu_parity import _custom_world
