@@ -189,6 +189,10 @@ FILM_CASES = [
     ("s1", 32, 16, 1, 2, {"max_marches": 12, "max_vis_marches": 5}),  # march budgets exhausted: 't' is returned as a hit (src/sdf.rs:82)
     ("s1", 32, 16, 1, 2, {"sdf_detail_scale": 2.0, "world_radius": 20.0}),
     ("s3", 6, 4, 1024, 16, {"tile_size": (2, 2)}),   # config 5's regime: 4096 spp (the four-wave resolve's maximum), 16 bounces, moving camera (motion blur)
+    ("s1", 3, 2, 400, 5, {"tile_size": (2, 2)}),     # 1600 spp: k_resolve_blk<256, 8> (1025..2048 spp), not a power of two
+    ("s2", 2, 2, 512, 4, {"tile_size": (2, 2)}),     # 2048 spp exactly, volume
+    ("s1", 2, 2, 700, 6, {"tile_size": (2, 1)}),     # 2800 spp: k_resolve_blk<512, 8> with padding
+    ("s1", 4, 3, 150, 6, {"tile_size": (2, 2)}),     # 600 spp: k_resolve_blk<128, 8> with padding
     ("s1", 2, 1, 1100, 3, {"tile_size": (2, 1)}),    # 4400 spp: just above 4096, not a power of two (sixteen-wave resolve, mostly padding)
     ("s3", 4, 2, 2048, 6, {"tile_size": (2, 2)}),    # 8192 spp, moving camera
     ("s2", 2, 2, 4096, 4, {"tile_size": (2, 2)}),    # 16384 spp (the supported maximum), volume
