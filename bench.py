@@ -51,6 +51,10 @@ WORKLOADS = {
     "c5": ("s3", 7680, 4320, 1024, 16, "7680x4320, 4096 spp, 16 bounces, MandelBox SDF, moving camera with time-sampled motion blur "
            "[BASELINE configs[4], an 8-GPU config: 135.9 G paths; the reference's SDF itself is not time-dependent]"),
     "bulb": ("bulb", 1920, 1080, 64, 8, "1920x1080, 256 spp, 8 bounces, power-8 Mandelbulb SDF (EXTENSION: the fractal BASELINE.json names; not in the reference), volumes off"),
+    # the reference's OWN workload, the only thing rayn itself times (src/main.rs:47-82 on src/setup.rs:46-170 as shipped): here the first
+    # frame of a fresh context (cold_ms) is the number that corresponds to a rayn run, and the CPU leg renders the WHOLE frame in the GPU's own 16x16 tiles
+    "shipped": ("ship", 1280, 720, 2, 3, "1280x720, 8 spp (SAMPLES = 2), 3 bounces, MandelBox SDF + homogeneous volume, frame 1: the reference's shipped default "
+                "(src/main.rs:47-82, src/setup.rs:16-60)"),
     "mid": ("s1", 960, 540, 16, 8, "960x540, 64 spp, 8 bounces, MandelBox (profiling-sized)"),
     "small": ("s1", 480, 270, 4, 3, "480x270, 16 spp, 3 bounces, MandelBox (quick check)"),
 }
@@ -59,8 +63,8 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 2; 20 for the sub-100-ms workloads shipped / c1 / small)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames before them (default 1; 3 for shipped / c1 / small)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -70,9 +74,16 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo stages the gather through host memory)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks render on cuda:0 (RCCL refuses two ranks on one device: use with --backend gloo)")
     ap.add_argument("--check-film", action="store_true", help="rank 0 re-renders the whole frame alone after the timed region and compares it bit for bit with the gathered film")
+    ap.add_argument("--gather-only", action="store_true", help="diagnosis of the N>1 exchange: render the frame once, then time 20 film gathers alone "
+                    "(barrier before each) and print per-rank / per-iteration gather times instead of the bench line - separates the xGMI gather from render skew")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barrier, all-reduce, FilmGather incl. rank 0's own block) even at "
                     "world size 1: executes the RCCL path of the multi-GPU launch on a one-GPU box")
     args = ap.parse_args()
+    quick = args.workload in ("shipped", "c1", "small")
+    if args.steps is None:
+        args.steps = 20 if quick else 2
+    if args.warmup is None:
+        args.warmup = 3 if quick else 1
 
     import numpy as np
     import torch
@@ -106,7 +117,7 @@ def main():
 
     scene, W, H, samples, bounces, desc = WORKLOADS[args.workload]
     spp = 4 * samples
-    cam, wld = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb}[scene]((W, H))
+    cam, wld = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
     wd = wld.to_desc(cam)
     p = rayn_amd.frame_params(W, H, samples, bounces, tile_first=rank, tile_step=world)
     tabs = rayn_amd.build_tables(spp, bounces, p.volume_marches, p.frame, W, H)
@@ -118,42 +129,100 @@ def main():
     ctx.upload_world(wd)
     ctx.set_fma_policy(args.fma_policy)
     cold_ms = None
+    cold_detail = None
     if not use_dist and not args.no_cold:
+        t_created = time.perf_counter()
         ctx.render_host(p, tabs)
         cold_ms = (time.perf_counter() - t_cold) * 1e3
+        cold_detail = {"context_ms": round((t_created - t_cold) * 1e3, 1), "first_frame_ms": round(cold_ms - (t_created - t_cold) * 1e3, 1),
+                       "note": "context_ms = rayn_hip_create (HIP runtime start-up of this process included) + upload_world; first_frame_ms = "
+                               "rayn_hip_render_frame on host buffers (tables up, arenas allocated, code objects loaded, film down)"}
     d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
     film = rayn_amd.film.alloc_device_film(W, H, device)
     gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo"), force=args.force_dist) if use_dist else None
 
-    def step():
+    # per-rank diagnosis of an N>1 run (all-gathered after the timed region): HIP-event time of the render (rayn_stats.ms_total, events
+    # on the caller's stream around the whole share), host wall time of the render call, and the gather (pack + collective + scatter,
+    # fenced with a device synchronise - the render call is blocking already, and the next frame follows the gather on the same stream,
+    # so the fence costs one host round trip)
+    acc = {"render_ms": 0.0, "render_wall_ms": 0.0, "gather_ms": 0.0}
+
+    def step(timed=False):
+        t_a = time.perf_counter()
         ctx.render_device(p, d_tabs, film)
+        t_b = time.perf_counter()
+        res = film
         if gather is not None:
-            return gather.gather(film)
-        return film
+            res = gather.gather(film)
+            torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        if timed:
+            acc["render_ms"] += ctx.stats()["ms_total"]
+            acc["render_wall_ms"] += (t_b - t_a) * 1e3
+            acc["gather_ms"] += (t_c - t_b) * 1e3
+        return res
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    xdev = device if args.backend == "nccl" else "cpu"
+
     def all_reduce(x, op):
-        t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        t = torch.tensor([x], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=op)
         return float(t.item())
+
+    def all_gather_vec(vec):
+        """[world][len(vec)] float64: every rank's vector on every rank (one all_gather)."""
+        mine = torch.tensor(vec, dtype=torch.float64, device=xdev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        return [[float(v) for v in t.tolist()] for t in parts]
+
+    if args.gather_only:
+        if not use_dist:
+            sys.exit("bench.py: --gather-only needs the process-group path (N > 1 ranks, or --force-dist)")
+        step()
+        iters = 20
+        mine = []
+        for _ in range(iters):
+            fence()
+            t_a = time.perf_counter()
+            gather.gather(film)
+            torch.cuda.synchronize()
+            mine.append((time.perf_counter() - t_a) * 1e3)
+        allr = all_gather_vec(mine)
+        if rank == 0:
+            print(json.dumps({"mode": "gather-only", "metric": "film gather (pack + one dist.gather + scatter on rank 0), ms", "n_gpus": world, "iterations": iters,
+                              "backend": args.backend, "bytes_per_rank": gather.block * 40, "pixels_per_rank": gather.counts,
+                              "rank0_ms": [round(v, 3) for v in allr[0]], "per_rank_mean_ms": [round(sum(r) / len(r), 3) for r in allr],
+                              "per_rank_min_ms": [round(min(r), 3) for r in allr], "workload": desc}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        ctx.close()
+        return
 
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        result = step()
+        result = step(timed=True)
     fence()
     dt = time.perf_counter() - t0
     stats = ctx.stats()
     segments_per_step = stats["segments"]
+    per_rank = None
     if use_dist:
         dt = all_reduce(dt, dist.ReduceOp.MAX)
         segments_per_step = int(all_reduce(float(stats["segments"]), dist.ReduceOp.SUM))  # every rank's own share (exact below 2^53)
+        rows = all_gather_vec([acc["render_ms"] / args.steps, acc["render_wall_ms"] / args.steps, acc["gather_ms"] / args.steps,
+                               float(stats["segments"]), float(stats["batches"]), float(stats["tiles"])])
+        per_rank = {"render_ms": [round(r[0], 3) for r in rows], "render_wall_ms": [round(r[1], 3) for r in rows],
+                    "gather_ms": [round(r[2], 3) for r in rows], "segments": [int(r[3]) for r in rows], "batches": [int(r[4]) for r in rows],
+                    "tiles": [int(r[5]) for r in rows]}
     film_check = None
     if use_dist and args.check_film and rank == 0:  # outside the timed region: the whole frame on this rank alone
         p_full = rayn_amd.frame_params(W, H, samples, bounces)
@@ -215,21 +284,22 @@ def main():
             roofline_hbm["kernels"][name] = {"ms": round(ms_k, 3), "algorithmic_bytes": nbytes, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
         # PMC traffic is measured by separate rocprofv3 --pmc passes (tools/gpu_round.sh) and committed under profiles/ with the
         # hash of the kernel sources it was taken on; a file that does not match the sources of THIS build is not quoted.
-        pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_hbm_{args.workload}.json")
-        if os.path.exists(pmc_path) and world == 1 and args.fma_policy == 0:
+        pmc_name = next((n for n in (f"r04_pmc_hbm_{args.workload}.json", f"r03_pmc_hbm_{args.workload}.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name or "")
+        if pmc_name and world == 1 and args.fma_policy == 0:
             pj = json.load(open(pmc_path))
             if pj.get("source_hash") == kernel_source_hash():
                 pmc = pj["kernels"]
                 if kname in pmc and "hbm_bytes_per_launch" in pmc[kname]:
                     roofline["traffic"] = pmc[kname]["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = f"profiles/r03_pmc_hbm_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, kernel sources {pj['source_hash']})"
+                    roofline["traffic_source"] = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, kernel sources {pj['source_hash']})"
                 if kname in pmc and "valu_inst_per_cycle_simd" in pmc[kname]:
                     # same file, same kernel sources: SQ counters of the dominant kernel.  A wave64 binary32 VALU instruction issues at
                     # one per 2 cycles per SIMD (what the 157.3 TFLOP/s peak is made of: 64 lanes x 2 flop / 2 cycles x 1024 SIMDs x 2.4 GHz)
                     ipc = pmc[kname]["valu_inst_per_cycle_simd"]
                     roofline["valu_issue"] = {"inst_per_cycle_simd": round(ipc, 4), "peak": 0.5, "frac": round(ipc / 0.5, 4),
                                               "lanes_enabled": round(pmc[kname]["lanes_enabled"], 4),
-                                              "source": f"profiles/r03_pmc_hbm_{args.workload}.json (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
+                                              "source": f"profiles/{pmc_name} (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
                 roofline_hbm["pmc_traffic"] = {k: {"hbm_bytes": v["hbm_bytes"], "GBps": round(v.get("hbm_GBps", 0.0), 1)} for k, v in pmc.items()}
                 # k_shade_finish has no closed-form algorithmic byte count (its records exist per light-receiving hit): it is rated on
                 # the MEASURED traffic of the same kernel sources (PMC pass) over the live HIP-event time of this run
@@ -238,7 +308,7 @@ def main():
                     ach = fin["hbm_bytes"] / (st["ms_finish"] * 1e-3) / 1e9
                     roofline_hbm["kernels"]["k_shade_finish (PMC-measured HBM bytes)"] = {"ms": round(st["ms_finish"], 3), "hbm_bytes": fin["hbm_bytes"], "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
             else:
-                roofline["traffic_note"] = f"profiles/r03_pmc_hbm_{args.workload}.json was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"
+                roofline["traffic_note"] = f"profiles/{pmc_name} was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"
         kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_shadow", "ms_finish", "ms_compact", "ms_resolve", "ms_total")}
     else:
         kernel_ms = None
@@ -255,6 +325,7 @@ def main():
         ct = 16
         while ct > 1 and ct * ct * spp > 4096:
             ct //= 2
+        whole_frame = W * H * spp <= (1 << 23)  # the shipped workload (7.4 M paths): the CPU leg renders the WHOLE frame in the GPU's own 16x16 tiles
         p0 = rayn_amd.frame_params(W, H, samples, bounces, tile_size=(ct, ct))
         n_tiles = rayn_amd._lib.lib().rayn_tile_count(W, H, p0.tile_w, p0.tile_h)
         # calibrate on one spread tile per thread, then run whole rounds of tiles per thread for ~cpu_seconds (>= 3 rounds, so that
@@ -264,15 +335,25 @@ def main():
             t = time.perf_counter()
             _, ctr = O.render(wd, p0, tabs, threads=threads, tile_subset=sub)
             return time.perf_counter() - t, ctr.paths, len(sub)
-        t_cal, paths_cal, k_cal = run(threads)
-        rounds = int(min(32, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))
-        k = int(min(n_tiles, threads * rounds))
-        t_cpu, paths_cpu, k_used = run(k)
-        cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
-                        "tile": [ct, ct], "gpu_tile": [p.tile_w, p.tile_h],
-                        "sample": f"{k_used} of {n_tiles} {ct}x{ct}-pixel tiles (evenly spread, {paths_cpu} paths) of the same workload, C++ oracle "
-                                  f"(restatement of rayn's CPU path; rayn itself cannot be built here), {t_cpu:.1f} s; the GPU renders "
-                                  f"{p.tile_w}x{p.tile_h} tiles (same per-path work, different packet grouping)"}
+        if whole_frame:
+            t_w = time.perf_counter()
+            _, ctr_w = O.render(wd, p, tabs, threads=threads)
+            t_w = time.perf_counter() - t_w
+            cpu_baseline = {"value": round(ctr_w.paths / t_w / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
+                            "tile": [p.tile_w, p.tile_h], "gpu_tile": [p.tile_w, p.tile_h], "frame_ms": round(t_w * 1e3, 1),
+                            "sample": f"the WHOLE frame ({ctr_w.tiles} tiles of {p.tile_w}x{p.tile_h} pixels = the GPU's own tiles and packet grouping, {ctr_w.paths} paths, "
+                                      f"{ctr_w.segments} segments), C++ oracle (restatement of rayn's CPU path; rayn itself cannot be built here), "
+                                      f"{threads} threads, one tile per task like the reference's rayon pool, {t_w:.1f} s"}
+        else:
+            t_cal, paths_cal, k_cal = run(threads)
+            rounds = int(min(32, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))
+            k = int(min(n_tiles, threads * rounds))
+            t_cpu, paths_cpu, k_used = run(k)
+            cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
+                            "tile": [ct, ct], "gpu_tile": [p.tile_w, p.tile_h],
+                            "sample": f"{k_used} of {n_tiles} {ct}x{ct}-pixel tiles (evenly spread, {paths_cpu} paths) of the same workload, C++ oracle "
+                                      f"(restatement of rayn's CPU path; rayn itself cannot be built here), {t_cpu:.1f} s; the GPU renders "
+                                      f"{p.tile_w}x{p.tile_h} tiles (same per-path work, different packet grouping)"}
 
     if rank == 0:
         out = {
@@ -286,6 +367,18 @@ def main():
             "cold_ms": None if cold_ms is None else round(cold_ms, 1),  # fresh context -> first frame done (host buffers), see above
         }
         out["config"]["build_variant"] = rayn_amd._lib.build_variant() or "product"
+        out["config"]["resolve_kernel"] = ("k_resolve_reg<%d>" % max(1, 1 << max(0, (spp - 1).bit_length() - 6)) if spp <= 512 else
+                                           "k_resolve_blk<128, 8>" if spp <= 1024 else "k_resolve_blk<256, 8>" if spp <= 2048 else
+                                           "k_resolve_blk<512, 8>" if spp <= 4096 else "k_resolve_huge")
+        if cold_detail is not None:
+            out["cold_detail"] = cold_detail
+        if per_rank is not None:
+            # what the first real multi-GPU run needs to be diagnosable: every rank's render time (HIP events around its share), its
+            # gather time, its share of the work; gather_ms = rank 0's (the receiver: pack + collective + scatter of N - 1 blocks)
+            out["per_rank"] = per_rank
+            out["gather_ms"] = per_rank["gather_ms"][0]
+            mean_r = sum(per_rank["render_ms"]) / len(per_rank["render_ms"])
+            out["imbalance"] = round(max(per_rank["render_ms"]) / mean_r, 4) if mean_r > 0 else None
         if film_check is not None:
             out["film_check"] = film_check  # gathered film == single-rank film, bit for bit
         if use_dist and args.backend != "nccl":

@@ -632,6 +632,212 @@ edit("src/filter.rs", """pub struct FilterImportanceSampler {
 }
 """)
 
+# ---- RAYN_DUMP=<dir>[,<tile>]: the observable state of one render in tools/rayn_dump.py's format (N2, INTEGRATION.md 4a) -------
+# src/dump.rs is a NEW file carried by the patch; src/film.rs writes through it, src/hitable.rs exposes the bin lengths.
+NEW_FILES = {}
+NEW_FILES["src/dump.rs"] = """//! RAYN_DUMP=<dir>[,<tile>] - write what one `Film::render_frame_into` consumed and produced as raw little-endian arrays
+//! (the format of librayn_hip's tools/rayn_dump.py, which then diffs two such directories array by array):
+//!   samples_1d.f32 samples_2d.f32   Samples::new_rd tables                               src/sampler.rs:18-37
+//!   scramble.f32                    SmallRng::seed_from_u64(x + y*w).gen::<f32>()        src/film.rs:460-461
+//!   fis.f32                         FilterImportanceSampler::inverse_cdf (512)           src/filter.rs:187-220
+//!   color / alpha / background / normal .f32   the film after tile_finished, index x + y*w (y = 0 is the bottom row)
+//!   trace.u32                       tile <tile>'s per-depth packet lanes in HitStore::process_hits order, 6 u32 per lane:
+//!                                   depth, object id, tile x, tile y, sample, valid      src/hitable.rs:94-134
+//!   manifest.json                   the parameters the comparer checks first
+//! Unset = no effect.  The dump happens inside the frame: do not time a frame that dumps.
+use std::io::Write;
+
+pub struct DumpCfg {
+    pub dir: String,
+    pub tile: usize,
+}
+
+/// `RAYN_DUMP=<dir>[,<tile>]` (tile defaults to 1, like tools/rayn_dump.py's --tile)
+pub fn config() -> Option<DumpCfg> {
+    let v = std::env::var("RAYN_DUMP").ok()?;
+    let mut parts = v.splitn(2, ',');
+    let dir = parts.next()?.to_string();
+    let tile = parts.next().and_then(|t| t.trim().parse().ok()).unwrap_or(1);
+    std::fs::create_dir_all(&dir).ok()?;
+    Some(DumpCfg { dir, tile })
+}
+
+pub fn write_f32(dir: &str, name: &str, v: &[f32]) {
+    let mut bytes = Vec::with_capacity(v.len() * 4);
+    for x in v {
+        bytes.extend_from_slice(&x.to_bits().to_le_bytes());
+    }
+    std::fs::write(format!("{}/{}.f32", dir, name), bytes).unwrap();
+}
+
+pub fn write_u32(dir: &str, name: &str, v: &[u32]) {
+    let mut bytes = Vec::with_capacity(v.len() * 4);
+    for x in v {
+        bytes.extend_from_slice(&x.to_le_bytes());
+    }
+    std::fs::write(format!("{}/{}.u32", dir, name), bytes).unwrap();
+}
+
+#[allow(clippy::too_many_arguments)]
+pub fn write_manifest(
+    cfg: &DumpCfg,
+    width: u32,
+    height: u32,
+    samples: usize,
+    max_bounces: usize,
+    volume_marches: usize,
+    frame: usize,
+    time_start: f32,
+    time_end: f32,
+    tile_w: u32,
+    tile_h: u32,
+) {
+    let mut f = std::fs::File::create(format!("{}/manifest.json", cfg.dir)).unwrap();
+    write!(
+        f,
+        "{{\\"scene\\": \\"rayn setup::setup()\\", \\"width\\": {}, \\"height\\": {}, \\"SAMPLES\\": {}, \\"spp\\": {}, \\"max_bounces\\": {}, \\"volume_marches\\": {}, \\"frame\\": {}, \\"time_range\\": [{:e}, {:e}], \\"tile\\": [{}, {}], \\"trace_tile\\": {}, \\"backend\\": \\"rayn\\"}}\\n",
+        width,
+        height,
+        samples,
+        4 * samples,
+        max_bounces,
+        volume_marches,
+        frame,
+        time_start,
+        time_end,
+        tile_w,
+        tile_h,
+        cfg.tile
+    )
+    .unwrap();
+}
+"""
+edit("src/main.rs", "mod camera;\n", "mod camera;\nmod dump;\n")
+edit("src/hitable.rs", """    pub fn reset(&mut self) {
+        for hit in self.hits.iter_mut() {
+            hit.clear();
+        }
+    }
+""", """    pub fn reset(&mut self) {
+        for hit in self.hits.iter_mut() {
+            hit.clear();
+        }
+    }
+
+    /// Length of every object's bin (after `process_hits`: padded to a multiple of 4 = whole packets), in object order.
+    pub fn bin_lens<'a>(&'a self) -> impl Iterator<Item = usize> + 'a {
+        self.hits.iter().map(|hits| hits.len())
+    }
+""")
+edit("src/film.rs", """        let width = self.res.w;
+
+        self.integrate_tiles(tiles, samples * 4, |tile| {
+""", """        let width = self.res.w;
+
+        // RAYN_DUMP=<dir>[,<tile>] (src/dump.rs): the tables this frame reads, one tile's packets, the film it leaves
+        let dump_cfg = crate::dump::config();
+        if let Some(cfg) = &dump_cfg {
+            crate::dump::write_f32(&cfg.dir, "samples_1d", &sample_sets.samples_1d);
+            crate::dump::write_f32(&cfg.dir, "samples_2d", &sample_sets.samples_2d);
+            crate::dump::write_f32(&cfg.dir, "fis", &fis.inverse_cdf);
+            let mut scramble = Vec::with_capacity((self.res.w * self.res.h) as usize);
+            for y in 0..self.res.h {
+                for x in 0..self.res.w {
+                    let mut rng = SmallRng::seed_from_u64((x + y * width) as u64);
+                    scramble.push(rng.gen::<f32>());
+                }
+            }
+            crate::dump::write_f32(&cfg.dir, "scramble", &scramble);
+            crate::dump::write_manifest(
+                cfg,
+                self.res.w,
+                self.res.h,
+                samples,
+                crate::setup::MAX_INDIRECT_BOUNCES,
+                VOLUME_MARCHES_PER_SAMPLE,
+                frame,
+                time_range.start,
+                time_range.end,
+                tile_size.w,
+                tile_size.h,
+            );
+        }
+        let dump_ref = dump_cfg.as_ref();
+
+        self.integrate_tiles(tiles, samples * 4, |tile| {
+            let trace_this = dump_ref.map_or(false, |cfg| cfg.tile == tile._index);
+            let mut trace: Vec<u32> = Vec::new();
+""")
+edit("src/film.rs", """                hit_store.process_hits(&world.hitables, &mut wintersections, &half_pixel_size_at);
+""", """                hit_store.process_hits(&world.hitables, &mut wintersections, &half_pixel_size_at);
+
+                if trace_this {
+                    // wintersections is object-major, every object's bin padded to whole packets (src/hitable.rs:94-134)
+                    let mut k = 0;
+                    for (obj_id, bin_len) in hit_store.bin_lens().enumerate() {
+                        for _ in 0..bin_len / 4 {
+                            let (_mat, wsp) = &wintersections[k];
+                            k += 1;
+                            for lane in 0..4 {
+                                trace.extend_from_slice(&[
+                                    depth as u32,
+                                    obj_id as u32,
+                                    wsp.ray.tile_coord[lane].x,
+                                    wsp.ray.tile_coord[lane].y,
+                                    wsp.ray.sample[lane] as u32,
+                                    wsp.ray.valid[lane] as u32,
+                                ]);
+                            }
+                        }
+                    }
+                }
+""")
+edit("src/film.rs", """                    spawned_wrays.push(wray);
+                }
+                spawned_rays.clear();
+            }
+        });
+    }
+""", """                    spawned_wrays.push(wray);
+                }
+                spawned_rays.clear();
+            }
+
+            if trace_this {
+                if let Some(cfg) = dump_ref {
+                    crate::dump::write_u32(&cfg.dir, "trace", &trace);
+                }
+            }
+        });
+
+        if let Some(cfg) = &dump_cfg {
+            self.dump_channels(&cfg.dir);
+        }
+    }
+
+    /// The film after `tile_finished` (src/film.rs:660-691) as flat f32 arrays, index x + y*w, y = 0 the bottom row.
+    fn dump_channels(&self, dir: &str) {
+        let channels = self.channels.lock().unwrap();
+        for channel in channels.iter() {
+            match channel {
+                ChannelStorage::Color(buf) => {
+                    let flat: Vec<f32> = buf.iter().flat_map(|s| vec![s.x, s.y, s.z]).collect();
+                    crate::dump::write_f32(dir, "color", &flat);
+                }
+                ChannelStorage::Alpha(buf) => crate::dump::write_f32(dir, "alpha", buf),
+                ChannelStorage::Background(buf) => {
+                    let flat: Vec<f32> = buf.iter().flat_map(|s| vec![s.x, s.y, s.z]).collect();
+                    crate::dump::write_f32(dir, "background", &flat);
+                }
+                ChannelStorage::WorldNormal(buf) => {
+                    let flat: Vec<f32> = buf.iter().flat_map(|s| vec![s.x, s.y, s.z]).collect();
+                    crate::dump::write_f32(dir, "normal", &flat);
+                }
+            }
+        }
+    }
+""")
+
 
 def main():
     tmp = tempfile.mkdtemp(prefix="rayn_patch_")
@@ -646,6 +852,9 @@ def main():
                 assert text.count(old) == count, f"{path}: expected {count} occurrence(s) of {old!r}, found {text.count(old)}"
                 text = text.replace(old, new)
             open(f, "w").write(text)
+        for path, text in NEW_FILES.items():
+            assert not os.path.exists(os.path.join(tmp, "a", path)), path
+            open(os.path.join(tmp, "b", path), "w").write(text)
         r = subprocess.run(["diff", "-ruN", "a/src", "b/src"], cwd=tmp, capture_output=True, text=True)
         assert r.returncode == 1, r.stderr
         # drop diff's timestamps: the patch should not change from run to run
@@ -655,6 +864,8 @@ def main():
                 continue
             if ln.startswith(("--- a/", "+++ b/")):
                 ln = ln.split("\t")[0] + "\n"
+                if ln.startswith("--- a/") and ln[6:].strip() in NEW_FILES:
+                    ln = "--- /dev/null\n"  # a file the patch creates (git apply wants the null source)
             lines.append(ln)
         open(OUT, "w").write("".join(lines))
         print(f"wrote {OUT}: {len(lines)} lines, {len(EDITS)} files")

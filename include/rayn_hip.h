@@ -279,8 +279,13 @@ int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths);
  * profiles/r03_cold_start.txt).  The FIRST frame a context renders therefore sizes its batches for arenas of at most `bytes`
  * in total (default 44 GB: one worker with 2^26-path batches of the volume path, 2^27 without - a quarter of the full size,
  * 2.5 % slower); from its second frame on a context uses full-size batches.  The
- * result is bit-identical (batching never changes a pixel: packets are per tile).  0 = full size from the first frame; also
- * RAYN_HIP_COLD_BYTES at context creation. */
+ * result is bit-identical (batching never changes a pixel: packets are per tile).  0 = full size from the first frame.
+ *
+ * Environment.  The library reads NO tuning from the environment unless RAYN_HIP_ENV_TUNING=1 is exported at context creation
+ * (the measurement scripts under tools/ do); then RAYN_HIP_WORKERS, RAYN_HIP_WORKER_MIN_PATHS, RAYN_HIP_BATCH_PATHS,
+ * RAYN_HIP_COLD_BYTES, RAYN_HIP_PROFILE (per-launch HIP events = rayn_hip_set_profiling), RAYN_HIP_REFILL_EXTEND / _SHADOW,
+ * RAYN_HIP_PREFETCH_EXTEND / _SHADOW, RAYN_HIP_FAST_PATH and RAYN_HIP_PERSISTENT_BLOCKS preset the corresponding launch
+ * parameters of a new context.  None of them changes a pixel. */
 int rayn_hip_set_cold_bytes(rayn_ctx* ctx, uint64_t bytes);
 /* mul_add policy (include/rayn_detmath.h): 0 = unfused a*b+c, what rayn's default x86-64 build does (wide
  * 0.4.6 without +fma) — the DEFAULT; 1 = fused, what rayn built with -C target-feature=+fma does.

@@ -52,6 +52,20 @@
  *      f32 * / + - and tan().  This file never sees them: it consumes the flattened POD.  The host mirrors that build the POD
  *      (rayn_amd/scene.py normalized(), include/rayn_host.hpp Vec3::normalized) evaluate the fused form unconditionally; for
  *      the shipped constants every product is exact, so the POD is the same either way (tests/test_oracle.py).
+ *
+ * ALTERNATIVE READINGS (round 4; oracle/SENSITIVITY.md).  Each assumption above that can change a pixel has a build switch
+ * that compiles the OTHER plausible reading into a variant library (oracle/Makefile `variants`; never the default, never used
+ * by the parity tests): whoever has a Rust toolchain runs tools/pin_against_rayn.sh, and if the default disagrees with rayn,
+ * the variant that agrees names the assumption that was wrong.  oracle/sensitivity.py measures how far each variant moves
+ * whole frames, i.e. which assumptions exceed north_star's per-pixel 1e-4 and must be checked first.
+ *   RAYN_ORACLE_ALT_MINMAX=1   A2: a.max(b) = maxps(b, a) (operands swapped: a when unordered / both zero)
+ *   RAYN_ORACLE_ALT_MINMAX=2   A2: lane-wise f32::max / f32::min (IEEE maxNum / minNum: the non-NaN operand)
+ *   RAYN_ORACLE_LIBM=1         A3: the host libm's expf / sinf / cosf / tanf / atan2f / powf (what lane-wise f32::exp etc. call on Linux)
+ *   RAYN_ORACLE_ALT_NORMALIZE=1 A4: normalized() divides the three components by mag instead of multiplying by 1 / mag
+ *   RAYN_ORACLE_ALT_DOT=1      A4: dot = (x*ox + y*oy) + z*oz, plain left-to-right products and sums (no mul_add nesting)
+ *   RAYN_ORACLE_ALT_NORMALS=1  A5: central differences (sdfu `normals`, 6 evaluations) instead of the tetrahedral `normals_fast`
+ *   RAYN_ORACLE_ALT_NORMALS=2  A5: the tetrahedral estimator with the four terms summed in the order xxx, xyy, yxy, yyx
+ *   RAYN_ORACLE_ALT_LERP=1     A5: Lerp::lerp(a, b, t) = a + (b - a) * t
  */
 #include "../include/rayn_detmath.h"
 #define DMF_COUNT_FALLBACKS /* host check of the kernels' fast elementary functions (oracle_detmath_fast); the oracle's path does not use them */
@@ -108,8 +122,16 @@ inline M4 operator&(M4 a, M4 b) { return M4(a.q & b.q); }
 inline M4 operator!(M4 a) { return M4(~a.q); }
 inline F4 merge(M4 m, F4 t, F4 f) { return F4((f4v)(((i4v)t.q & m.q) | ((i4v)f.q & ~m.q))); }
 /* A2: SSE semantics: maxps(a, b) = a > b ? a : b (b when unordered or equal), minps likewise */
+#if !defined(RAYN_ORACLE_ALT_MINMAX) || RAYN_ORACLE_ALT_MINMAX == 0
 inline F4 fmax4(F4 a, F4 b) { return F4(__builtin_ia32_maxps(a.q, b.q)); }
 inline F4 fmin4(F4 a, F4 b) { return F4(__builtin_ia32_minps(a.q, b.q)); }
+#elif RAYN_ORACLE_ALT_MINMAX == 1 /* alternative reading: the intrinsic's operands the other way round */
+inline F4 fmax4(F4 a, F4 b) { return F4(__builtin_ia32_maxps(b.q, a.q)); }
+inline F4 fmin4(F4 a, F4 b) { return F4(__builtin_ia32_minps(b.q, a.q)); }
+#else /* alternative reading: lane-wise f32::max / f32::min = IEEE maxNum / minNum */
+inline F4 fmax4(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = __builtin_fmaxf(a.v[i], b.v[i]); return r; }
+inline F4 fmin4(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = __builtin_fminf(a.v[i], b.v[i]); return r; }
+#endif
 inline F4 abs4(F4 a) { return F4((f4v)((i4v)a.q & (i4v){0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff})); }
 inline F4 sqrt4(F4 a) { return F4(__builtin_ia32_sqrtps(a.q)); }
 inline F4 floor4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = __builtin_floorf(a.v[i]); return r; }
@@ -120,14 +142,27 @@ inline F4 mul_add(F4 a, F4 b, F4 c) { return F4(a.q * b.q + c.q); } /* A1: unfus
 #endif
 inline float signum1(float x) { return x != x ? x : __builtin_copysignf(1.0f, x); } /* A8 */
 inline F4 signum4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = signum1(a.v[i]); return r; }
+#if defined(RAYN_ORACLE_LIBM) && RAYN_ORACLE_LIBM /* alternative reading of A3: the platform libm, lane by lane */
+inline F4 exp4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = ::expf(a.v[i]); return r; }
+inline F4 tan4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = ::tanf(a.v[i]); return r; }
+inline F4 atan2_4(F4 y, F4 x) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = ::atan2f(y.v[i], x.v[i]); return r; }
+inline F4 powf4(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = ::powf(a.v[i], b.v[i]); return r; }
+inline void sin_cos4(F4 a, F4* s, F4* c) { for (int i = 0; i < 4; i++) { s->v[i] = ::sinf(a.v[i]); c->v[i] = ::cosf(a.v[i]); } }
+#else
 inline F4 exp4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = dm_expf(a.v[i]); return r; }
 inline F4 tan4(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = dm_tanf(a.v[i]); return r; }
 inline F4 atan2_4(F4 y, F4 x) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = dm_atan2f(y.v[i], x.v[i]); return r; }
 inline F4 powf4(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = dm_powf(a.v[i], b.v[i]); return r; }
 inline void sin_cos4(F4 a, F4* s, F4* c) { for (int i = 0; i < 4; i++) dm_sincosf(a.v[i], &s->v[i], &c->v[i]); }
+#endif
 inline F4 powi5(F4 a) { F4 r; for (int i = 0; i < 4; i++) { float x = a.v[i], x2 = x * x; r.v[i] = (x2 * x2) * x; } return r; } /* powi(5) */
+#if defined(RAYN_ORACLE_ALT_LERP) && RAYN_ORACLE_ALT_LERP /* alternative reading of A5 */
+inline F4 lerp4(F4 a, F4 b, F4 t) { return a + (b - a) * t; }
+inline float lerp1(float a, float b, float t) { return a + (b - a) * t; }
+#else
 inline F4 lerp4(F4 a, F4 b, F4 t) { return a * (F4(1.0f) - t) + b * t; } /* A5 */
 inline float lerp1(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+#endif
 
 const float PI_F = 3.14159265358979323846f;
 const float TWO_PI_F = 6.28318530717958647692f;
@@ -154,10 +189,18 @@ inline W3 operator-(W3 a) { return W3(-a.x, -a.y, -a.z); }
 inline W3& operator+=(W3& a, W3 b) { a = a + b; return a; }
 inline W3& operator*=(W3& a, F4 s) { a = a * s; return a; }
 inline W3& operator/=(W3& a, F4 s) { a = a / s; return a; }
+#if defined(RAYN_ORACLE_ALT_DOT) && RAYN_ORACLE_ALT_DOT /* alternative reading of A4: plain products summed left to right */
+inline F4 dot(W3 a, W3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#else
 inline F4 dot(W3 a, W3 b) { return mul_add(a.x, b.x, mul_add(a.y, b.y, a.z * b.z)); }
+#endif
 inline F4 mag_sq(W3 a) { return dot(a, a); }
 inline F4 mag(W3 a) { return sqrt4(mag_sq(a)); }
+#if defined(RAYN_ORACLE_ALT_NORMALIZE) && RAYN_ORACLE_ALT_NORMALIZE /* alternative reading of A4: three divisions */
+inline W3 normalized(W3 a) { F4 m = mag(a); return W3(a.x / m, a.y / m, a.z / m); }
+#else
 inline W3 normalized(W3 a) { F4 r_mag = F4(1.0f) / mag(a); return W3(a.x * r_mag, a.y * r_mag, a.z * r_mag); }
+#endif
 inline W3 cross(W3 a, W3 b) {
     return W3(mul_add(a.y, b.z, -a.z * b.y), mul_add(a.z, b.x, -a.x * b.z), mul_add(a.x, b.y, -a.y * b.x));
 }
@@ -426,10 +469,24 @@ struct TracedSDF : Hitable {
     }
     W3 normal_at(W3 p, F4 eps, float t0) const { /* sdfu normals_fast (A5), called at src/sdf.rs:94-96 */
         F4 o(1.0f), n(-1.0f);
+#if defined(RAYN_ORACLE_ALT_NORMALS) && RAYN_ORACLE_ALT_NORMALS == 1 /* alternative reading of A5: central differences (sdfu `normals`) */
+        F4 z(0.0f);
+        (void)n;
+        W3 ex(eps * o, z, z), ey(z, eps * o, z), ez(z, z, eps * o);
+        W3 g(sdf->dist_at(p + ex, t0) - sdf->dist_at(p - ex, t0), sdf->dist_at(p + ey, t0) - sdf->dist_at(p - ey, t0),
+             sdf->dist_at(p + ez, t0) - sdf->dist_at(p - ez, t0));
+        return normalized(g);
+#elif defined(RAYN_ORACLE_ALT_NORMALS) && RAYN_ORACLE_ALT_NORMALS == 2 /* alternative reading of A5: same estimator, other summation order */
+        W3 xyy(o, n, n), yyx(n, n, o), yxy(n, o, n), xxx(o, o, o);
+        W3 g = xxx * sdf->dist_at(p + xxx * eps, t0) + xyy * sdf->dist_at(p + xyy * eps, t0) +
+               yxy * sdf->dist_at(p + yxy * eps, t0) + yyx * sdf->dist_at(p + yyx * eps, t0);
+        return normalized(g);
+#else
         W3 xyy(o, n, n), yyx(n, n, o), yxy(n, o, n), xxx(o, o, o);
         W3 g = xyy * sdf->dist_at(p + xyy * eps, t0) + yyx * sdf->dist_at(p + yyx * eps, t0) +
                yxy * sdf->dist_at(p + yxy * eps, t0) + xxx * sdf->dist_at(p + xxx * eps, t0);
         return normalized(g);
+#endif
     }
     ShadingInfo get_shading_info(const WHit& hit, const ThresholdFn& hps) const override { /* :85-101 */
         W3 point = hit.point();

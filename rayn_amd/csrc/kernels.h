@@ -101,7 +101,7 @@ struct Tables {
     void launch_group_hist(hipStream_t s, uint32_t nclass, const uint8_t* ent_obj, uint32_t max_entries, const DCtl* ctl, uint8_t* grp_cnt); \
     void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt, \
                           const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total, \
-                          uint32_t* tile_valid, uint32_t* tile_cls_cnt);                            \
+                          uint32_t* tile_valid, uint32_t* tile_cls_cnt, const DCtl* ctl);           \
     void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base, \
                             uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt, \
                             uint32_t* tile_cls_base, uint32_t cap_groups);                          \

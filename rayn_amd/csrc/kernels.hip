@@ -378,7 +378,10 @@ __global__ void __launch_bounds__(256) k_scan_tile(uint32_t nclass, uint32_t str
                                                     const uint32_t* __restrict__ tile_grp_begin, const uint32_t* __restrict__ tile_grp_count,
                                                     uint32_t* __restrict__ grp_base, uint32_t* __restrict__ grp_tile,
                                                     uint32_t* __restrict__ tile_total, uint32_t* __restrict__ tile_valid,
-                                                    uint32_t* __restrict__ tile_cls_cnt) {
+                                                    uint32_t* __restrict__ tile_cls_cnt, const DCtl* __restrict__ ctl) {
+    // After an overflow (k_tile_prefix; cannot happen by the host's sizing) the group ranges of the tiles describe a queue that was
+    // never written: nothing downstream may index with them.  The flag is sticky, every later stage of the share sees size 0.
+    if (ctl->overflow) return;
     // Each WAVE owns whole classes (c = wave, wave + 4, ..) and walks the tile's groups 64 at a time with a wave scan and a
     // scalar running total: no block barrier inside the walk (the block-wide version spent its time in __syncthreads).
     // grp_base stays CLASS-relative; the class offsets are added by the scatter through tile_cls_base (k_tile_prefix).
@@ -478,7 +481,10 @@ __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const ui
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (s_run > cap_groups) { ctl->overflow |= 1u << stage; s_run = 0; s_valid = 0; } // cannot happen by the host's sizing; never write past a queue
+        // cannot happen by the host's sizing; never write past a queue - and once it has happened every later stage of the share is
+        // empty (the group ranges written above may exceed the arrays they index: k_scan_tile and the scatters return on the flag)
+        if (s_run > cap_groups) ctl->overflow |= 1u << stage;
+        if (ctl->overflow) { s_run = 0; s_valid = 0; }
         if (stage == 0) {
             ctl->entries_sum += (unsigned long long)ctl->q_groups << 6;
             ctl->b_groups = s_run; ctl->b_valid = s_valid;
@@ -601,13 +607,11 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
 RD bool all_zero(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 constexpr uint32_t VOL_MEMO_LIGHTS = 7; // per-light volume terms memoised in LDS (3 floats per light and thread)
 
-#ifndef RAYN_SETUP_WAVES
-#define RAYN_SETUP_WAVES 6 // waves per SIMD the register budget of k_shade_setup is set for (80 VGPRs)
-#endif
+constexpr int SETUP_WAVES = 6; // waves per SIMD the register budget of k_shade_setup is set for (80 VGPRs; 5 / 7 / 8 measured slower)
 // One slot per thread over a grid sized for the batch's upper bound (surplus blocks exit at once; a grid-stride loop carries
 // j and the count across a body that already spills: +44 B of scratch, 22 % slower).
 template <bool COUNT>
-__global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
+__global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                       uint32_t depth, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl, Pool pool, Nee nee,
                                                       uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt,
                                                       unsigned long long* __restrict__ evals_out) {
@@ -857,10 +861,7 @@ __global__ void __launch_bounds__(256, RAYN_SETUP_WAVES) k_shade_setup(const DSc
 // thread = 16 K ids per atomic; (2) a uniform branch around every visibility load serialised them (load - wait - ballot, once
 // per group) - all loads of a trip are now issued before the first ballot.  Together: 16.5 -> 7.7 ms per 1/8 share of config 3
 // (3.5 TB/s); either one alone: 16.5 -> 15.5-16.2 ms.
-#ifndef RAYN_SCAN_ITEMS
-#define RAYN_SCAN_ITEMS 64
-#endif
-constexpr uint32_t SCAN_ITEMS = RAYN_SCAN_ITEMS;
+constexpr uint32_t SCAN_ITEMS = 64;
 __global__ void __launch_bounds__(256) k_shadow_list(Nee nee, uint32_t ns, DCtl* __restrict__ ctl) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
@@ -1804,8 +1805,8 @@ void launch_group_hist(hipStream_t s, uint32_t nclass, const uint8_t* ent_obj, u
 }
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
                       const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
-                      uint32_t* tile_valid, uint32_t* tile_cls_cnt) {
-    hipLaunchKernelGGL(k_scan_tile, dim3(n_tiles), dim3(256), 0, s, nclass, stride, pad, grp_cnt, tgb, tgc, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt);
+                      uint32_t* tile_valid, uint32_t* tile_cls_cnt, const DCtl* ctl) {
+    hipLaunchKernelGGL(k_scan_tile, dim3(n_tiles), dim3(256), 0, s, nclass, stride, pad, grp_cnt, tgb, tgc, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt, ctl);
 }
 void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
                         uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt,

@@ -105,7 +105,7 @@ class Context:
         self._chk(self._L.rayn_hip_set_batch_paths(self.h, int(n)))
 
     def set_cold_bytes(self, n):
-        """arena bytes per worker of the context's first frame (rayn_hip_set_cold_bytes); 0 = full-size batches from the first frame"""
+        """arena bytes of ALL workers together for the context's first frame (rayn_hip_set_cold_bytes, rayn_hip.h); 0 = full-size batches from the first frame"""
         self._chk(self._L.rayn_hip_set_cold_bytes(self.h, int(n)))
 
     def stats(self):

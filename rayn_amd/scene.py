@@ -40,6 +40,12 @@ def _fmaf(a, b, c):
     if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
         return f32(a * b + c)
     exact = Fraction(a) * Fraction(b) + Fraction(c)
+    # beyond the binary32 range IEEE fmaf returns +-inf (round to nearest: from max + half an ulp of max on), like the Rust scalar
+    fmax = Fraction(float(np.finfo(np.float32).max))
+    if abs(exact) >= fmax + Fraction(2) ** (127 - 24):
+        return f32(np.inf) if exact > 0 else f32(-np.inf)
+    if abs(exact) > fmax:
+        return f32(np.finfo(np.float32).max) if exact > 0 else f32(-np.finfo(np.float32).max)
     lo = f32(float(exact))  # rounded through binary64: right except when it sits next to a binary32 rounding tie
     cands = sorted({lo, np.nextafter(lo, f32(-np.inf)), np.nextafter(lo, f32(np.inf))}, key=float)
     best = min(cands, key=lambda x: (abs(Fraction(float(x)) - exact), int(np.float32(x).view(np.uint32)) & 1))  # nearest, ties to even

@@ -48,17 +48,34 @@ CONFIGS = {
     "c3": ("s2", 1920, 1080, 256, 8),
     "c4": ("s1", 3840, 2160, 256, 12),
     "c5": ("s3", 7680, 4320, 1024, 16),
+    # the fractal BASELINE.json names (extension scene, rayn_amd/setup.py::setup_bulb) at configs[1]'s size
+    "bulb": ("bulb", 1920, 1080, 64, 8),
+    # the reference's OWN workload: src/main.rs:47-82 (1280x720, SAMPLES = 2 -> 8 spp, 3 bounces, frame 1, 16x16 tiles) on
+    # src/setup.rs:46-170 as shipped (volumes on) - the WHOLE frame (3 600 tiles, 7.37 M paths)
+    "shipped": ("ship", 1280, 720, 2, 3),
 }
 # fused-policy entries: (base config whose tile list is reused)
-FMA_CONFIGS = {"c1_fma": "c1", "c3_fma": "c3"}
+FMA_CONFIGS = {"c1_fma": "c1", "c3_fma": "c3", "shipped_fma": "shipped"}
+# whole-frame entries that are too many tiles to list one by one: digests per tile COLUMN (the tile list is x-major,
+# src/film.rs:399-427, so a column is a run of consecutive tiles) + one digest of the whole film
+COLUMN_CONFIGS = ("shipped",)
 CHANNELS = ("color", "alpha", "background", "normal")
 
 
+def _code_only(text):
+    """C/C++ source without comments and with whitespace collapsed: the stamp follows the ARITHMETIC, not the prose
+    (a citation added to a comment must not make every fixture look stale)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return " ".join(text.split())
+
+
 def oracle_hash():
-    """sha256 over the sources that define the oracle's arithmetic."""
+    """sha256 over the comment-stripped sources that define the oracle's arithmetic."""
     h = hashlib.sha256()
     for f in ("oracle/rayn_oracle.cpp", "include/rayn_detmath.h", "include/rayn_hip.h"):
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+        h.update(_code_only(open(os.path.join(ROOT, f), "r").read()).encode())
     return h.hexdigest()[:16]
 
 
@@ -76,7 +93,7 @@ def world_and_params(name, samples=None):
     from rayn_amd import setup as S
     scene, W, H, smp, bounces = CONFIGS[base_config(name)]
     # s3 = config 5: moving camera (reference-supported closure) + moving fractal (TracedSDF transform_seq extension)
-    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3}[scene]((W, H))
+    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
     p = P.frame_params(W, H, smp if samples is None else samples, bounces)
     return world.to_desc(cam), p
 
@@ -89,7 +106,10 @@ def tile_rect(p, k):
 
 def tile_digests(film, p, k):
     """SHA-256 per channel over the tile's pixels (rows y0..y1, columns x0..x1 of the bottom-up film)."""
-    x0, y0, x1, y1 = tile_rect(p, k)
+    return rect_digests(film, *tile_rect(p, k))
+
+
+def rect_digests(film, x0, y0, x1, y1):
     out = {}
     for ch in CHANNELS:
         a = np.ascontiguousarray(film[ch][y0:y1, x0:x1], np.float32).copy()
@@ -97,6 +117,14 @@ def tile_digests(film, p, k):
         bits[np.isnan(a)] = 0x7FC00000
         out[ch] = hashlib.sha256(bits.tobytes()).hexdigest()
     return out
+
+
+def column_digests(film, p):
+    """Whole-frame entry: one digest set per tile column (tiles tx * ny .. tx * ny + ny - 1) and one over the whole film."""
+    nx = (p.width + p.width % p.tile_w) // p.tile_w
+    cols = [{"column": tx, "x": [tx * p.tile_w, min(tx * p.tile_w + p.tile_w, p.width)],
+             "sha256": rect_digests(film, tx * p.tile_w, 0, min(tx * p.tile_w + p.tile_w, p.width), p.height)} for tx in range(nx)]
+    return cols, rect_digests(film, 0, 0, p.width, p.height)
 
 
 def choose_tiles(name, n_pick, jobs, O):
@@ -128,19 +156,70 @@ def choose_tiles(name, n_pick, jobs, O):
     return out
 
 
+def rederive_cheap_part(name, c, O, threads=None):
+    """Re-derives with the oracle AS IT IS NOW what is affordable of a fixture entry and asserts it: the whole c1 frame, one tile
+    column of a column entry (45 tiles), the cheapest listed tile of every other entry (a sky tile: one segment per path).  The
+    expensive tiles are re-derived by the GPU tests (the kernels share no code with the oracle but the math header)."""
+    fma = is_fma(name)
+    wd, p = world_and_params(name)
+    tabs = O.build_tables(4 * p.samples, p.max_bounces, p.volume_marches, p.frame, p.width, p.height, fma=fma)
+    if base_config(name) == "c1":
+        film, ctr = O.render(wd, p, tabs, fma=fma, threads=threads)
+        assert {k: getattr(ctr, k) for k in ("paths", "segments", "packets", "dist_evals")} == c["frame_counts"]
+        for t in c["tiles"]:
+            assert tile_digests(film, p, t["tile"]) == t["sha256"], (name, t["tile"])
+    elif base_config(name) in COLUMN_CONFIGS:
+        ny = (p.height + p.height % p.tile_h) // p.tile_h
+        col = c["columns"][len(c["columns"]) // 2 - 3]  # a column through the fractal
+        tx = col["column"]
+        film, ctr = O.render(wd, p, tabs, fma=fma, threads=threads, tile_subset=list(range(tx * ny, tx * ny + ny)))
+        assert ctr.tiles == ny
+        assert rect_digests(film, col["x"][0], 0, col["x"][1], p.height) == col["sha256"], (name, tx)
+    elif base_config(name) != "c5":  # a c5 oracle call allocates a 1.3 GB film: left to the GPU test
+        t = min(c["tiles"], key=lambda t: (t["segments"], t["paths"]))
+        film, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[t["tile"]], fma=fma)
+        assert (ctr.paths, ctr.segments) == (t["paths"], t["segments"])
+        assert tile_digests(film, p, t["tile"]) == t["sha256"], (name, t["tile"])
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("configs", nargs="*", default=["c1", "c2", "c3", "c4", "c5", "c1_fma", "c3_fma"])
+    ap.add_argument("configs", nargs="*", default=["c1", "c2", "c3", "c4", "c5", "bulb", "shipped", "c1_fma", "c3_fma", "shipped_fma"])
     ap.add_argument("--tiles", type=int, default=12)
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--out", default=os.path.join(HERE, "config_digests.json"))
+    ap.add_argument("--restamp", action="store_true", help="after an oracle edit that did not change its arithmetic: re-derive the cheap part of every entry "
+                    "(as tests/test_config_digests.py does) and, only if every digest still matches, write the current oracle_hash into the entries")
     args = ap.parse_args()
     from oracle import oracle_py as O
     O.build()
     result = json.load(open(args.out)) if os.path.exists(args.out) else {}
+    if args.restamp:
+        for name, c in result.items():
+            rederive_cheap_part(name, c, O)
+            c["oracle_hash"] = oracle_hash()
+            print("restamped", name, flush=True)
+        json.dump(result, open(args.out, "w"), indent=1)
+        return
     for name in args.configs:
         t0 = time.time()
         fma = is_fma(name)
+        if base_config(name) in COLUMN_CONFIGS:  # the whole frame in one oracle call, all threads
+            wd, p = world_and_params(name)
+            tabs = O.build_tables(4 * p.samples, p.max_bounces, p.volume_marches, p.frame, p.width, p.height, fma=fma)
+            film, ctr = O.render(wd, p, tabs, threads=args.jobs, fma=fma)
+            cols, whole = column_digests(film, p)
+            scene, W, H, smp, bounces = CONFIGS[base_config(name)]
+            result[name] = {"scene": scene, "width": W, "height": H, "samples": smp, "spp": 4 * smp, "max_bounces": bounces,
+                            "volume_marches": p.volume_marches, "frame": p.frame, "tile": [p.tile_w, p.tile_h], "fma_policy": int(fma),
+                            "columns": cols, "frame_sha256": whole,
+                            "frame_counts": {k: getattr(ctr, k) for k in ("paths", "segments", "packets", "dist_evals", "tiles")},
+                            "alpha_mean": float(film["alpha"].mean()),
+                            "oracle": "oracle/rayn_oracle.cpp, " + ("FUSED mul_add (librayn_oracle_fma.so)" if fma else "unfused mul_add (librayn_oracle.so)"),
+                            "oracle_hash": oracle_hash(), "seconds": round(time.time() - t0, 1)}
+            json.dump(result, open(args.out, "w"), indent=1)
+            print(name, "done in", round(time.time() - t0, 1), "s:", result[name]["frame_counts"], flush=True)
+            continue
         # a fused entry re-renders the tile list of its base config (same tiles under both policies)
         tiles = [t["tile"] for t in result[base_config(name)]["tiles"]] if fma else choose_tiles(name, args.tiles, args.jobs, O)
         wd, p = world_and_params(name)

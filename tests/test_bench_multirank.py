@@ -22,7 +22,7 @@ def _free_port():
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [2, 3])
 def test_bench_two_ranks_one_gpu(ranks):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_BATCH_PATHS=str(1 << 22))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_ENV_TUNING="1", RAYN_HIP_BATCH_PATHS=str(1 << 22))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0",
            "--workload", "c1", "--backend", "gloo", "--share-gpu", "--check-film", "--cpu-seconds", "0", "--no-roofline"]
@@ -36,6 +36,39 @@ def test_bench_two_ranks_one_gpu(ranks):
     assert out["value"] > 0 and out["config"]["paths_per_step"] == 256 * 256 * 16
     # the all-reduced segment count of the partitioned frame == the count of the whole frame (c1 is deterministic)
     assert out["segments_per_step"] == json.load(open(os.path.join(ROOT, "tests", "golden", "config_digests.json")))["c1"]["frame_counts"]["segments"]
+    _check_per_rank(out, ranks)
+    assert sum(out["per_rank"]["tiles"]) == 256
+
+
+def _check_per_rank(out, ranks):
+    """The diagnosis keys of an N>1 line: every rank's HIP-event render time, wall time, gather time, segments, batches; rank 0's
+    gather time; the render imbalance max / mean."""
+    pr = out["per_rank"]
+    for k in ("render_ms", "render_wall_ms", "gather_ms", "segments", "batches", "tiles"):
+        assert len(pr[k]) == ranks, k
+    assert all(v > 0 for v in pr["render_ms"]) and all(w >= 0.5 * r for w, r in zip(pr["render_wall_ms"], pr["render_ms"]))
+    assert sum(pr["segments"]) == out["segments_per_step"] and all(b >= 1 for b in pr["batches"])
+    assert out["gather_ms"] == pr["gather_ms"][0] and out["gather_ms"] > 0
+    assert 1.0 <= out["imbalance"] < 10.0
+    # the ranks' own clocks must explain the line: slowest render + its gather <= the max-over-ranks step time (+ slack for the barrier)
+    assert max(pr["render_wall_ms"]) <= out["ms_per_step"] * 1.05 + 1.0
+
+
+@pytest.mark.gpu
+def test_bench_gather_only_two_ranks():
+    """--gather-only: the frame is rendered once, then 20 gathers are timed alone (barrier before each) - the exchange separated
+    from the render skew.  Two ranks on the one GPU over gloo (the xGMI hop itself needs the driver's 8-GPU node)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_ENV_TUNING="1", RAYN_HIP_BATCH_PATHS=str(1 << 22))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1", "--backend", "gloo", "--share-gpu", "--gather-only"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["mode"] == "gather-only" and out["n_gpus"] == 2 and out["iterations"] == 20
+    assert len(out["rank0_ms"]) == 20 and len(out["per_rank_mean_ms"]) == 2 and all(v > 0 for v in out["rank0_ms"])
+    assert sum(out["pixels_per_rank"]) == 256 * 256 and out["bytes_per_rank"] == max(out["pixels_per_rank"]) * 40
 
 
 @pytest.mark.gpu
@@ -56,6 +89,7 @@ def test_bench_rccl_code_path_world1():
     assert out["n_gpus"] == 1 and out["film_check"] is True
     assert "RCCL gather" in out["config"]["parallelism"] and "TEST MODE" not in out["config"]["parallelism"]
     assert out["segments_per_step"] > out["config"]["paths_per_step"]  # summed over ranks by all-reduce: every path has >= 1 segment
+    _check_per_rank(out, 1)
 
 
 @pytest.mark.gpu
@@ -71,7 +105,7 @@ def test_bench_line_contract_n1():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline", "cold_ms"):
+              "roofline", "cpu_baseline", "cold_ms", "cold_detail"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f32" and out["vs_baseline"] is None
     assert out["value"] > 0 and abs(out["value"] - out["config"]["paths_per_step"] / out["ms_per_step"] / 1e3) < 1e-2 * out["value"]
@@ -80,5 +114,7 @@ def test_bench_line_contract_n1():
     assert "k_extend1" in rf["kernel"] or "k_shadow1" in rf["kernel"] or "k_shade_setup" in rf["kernel"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "tiles" in cb["sample"]
-    assert out["cold_ms"] > 0 and out["config"]["build_variant"] == "product"
+    assert out["cold_ms"] > 0 and out["config"]["build_variant"] == "product" and out["config"]["resolve_kernel"] == "k_resolve_reg<1>"
+    assert abs(out["cold_detail"]["context_ms"] + out["cold_detail"]["first_frame_ms"] - out["cold_ms"]) < 0.2
+    assert "per_rank" not in out  # single-process line: no process group
     assert all(0 <= v["frac"] < 1.5 for v in out["roofline_hbm"]["kernels"].values())

@@ -85,8 +85,17 @@ def _force_worker(rank, world, port):
     for k, v in full.items():
         film[k][mine] = torch.from_numpy(v)[mine]
     g = FilmGather(W, H, (16, 16), rank, world, "cpu", force=True)
-    if rank == 0:  # force: rank 0's own block travels through the collective too - wipe it to prove it comes back
+    if rank == 0:  # force: rank 0's own block travels through the collective too - it is WIPED from the film right after it has been
+        # packed, so the assertions below hold only if the scatter of block 0 brings it back
         keep = {k: v.clone() for k, v in film.items()}
+        orig_pack = g.pack
+
+        def pack_then_wipe(f):
+            buf = orig_pack(f)
+            for k in f:
+                f[k][mine] = 0
+            return buf
+        g.pack = pack_then_wipe
     out = g.gather(film)
     if rank == 0:
         covered = np.concatenate([owned_pixels(W, H, 16, 16, r, world) for r in range(world)])

@@ -329,6 +329,7 @@ def test_tuning_variants_are_invisible(oracle, monkeypatch):
     wd, p = case("s2", 48, 32, 2, 3)
     tabs = _tables(oracle, p)
     ref, ctr = oracle.render(wd, p, tabs)
+    monkeypatch.setenv("RAYN_HIP_ENV_TUNING", "1")  # the library reads its tuning variables only under this opt-in (rayn_hip.h)
     for env in ({"RAYN_HIP_FAST_PATH": "0"}, {"RAYN_HIP_PREFETCH_SHADOW": "8", "RAYN_HIP_PREFETCH_EXTEND": "60"}, {"RAYN_HIP_FAST_PATH": "0", "RAYN_HIP_REFILL_SHADOW": "1", "RAYN_HIP_WORKERS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -343,6 +344,30 @@ def test_tuning_variants_are_invisible(oracle, monkeypatch):
                 monkeypatch.delenv(k)
         assert st["segments"] == ctr.segments and st["shadow_jobs"] > 0
         assert film_equal_bits(out, ref), env
+
+
+def test_env_tuning_is_opt_in(oracle, monkeypatch):
+    """A host that merely exports RAYN_HIP_BATCH_PATHS / RAYN_HIP_PROFILE does not change how its frames run: the library reads its
+    tuning variables only when RAYN_HIP_ENV_TUNING=1 is set at context creation (include/rayn_hip.h)."""
+    import rayn_amd
+    wd, p = case("s1", 64, 48, 2, 2)  # 24 576 paths in 12 tiles
+    tabs = _tables(oracle, p)
+    monkeypatch.setenv("RAYN_HIP_BATCH_PATHS", "4096")
+    monkeypatch.setenv("RAYN_HIP_PROFILE", "1")
+    monkeypatch.delenv("RAYN_HIP_ENV_TUNING", raising=False)
+    got = {}
+    for opt_in in (False, True):
+        if opt_in:
+            monkeypatch.setenv("RAYN_HIP_ENV_TUNING", "1")
+        ctx = rayn_amd.Context(0)
+        try:
+            ctx.upload_world(wd)
+            got[opt_in] = (ctx.render_host(p, tabs), ctx.stats())
+        finally:
+            ctx.close()
+    assert got[False][1]["batches"] == 1 and got[False][1]["ms_extend"] == 0.0   # ignored: one batch, no per-launch events
+    assert got[True][1]["batches"] >= 6 and got[True][1]["ms_extend"] > 0.0      # honoured under the opt-in
+    assert film_equal_bits(got[False][0], got[True][0])
 
 
 def test_tile_partition_union(gpu_ctx, oracle):

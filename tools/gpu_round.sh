@@ -3,9 +3,10 @@
 # usage: bash tools/gpu_round.sh <tag> [workloads...]      outputs under gpurun_out/ and profiles/${R}_*
 set -x
 TAG=${1:-v1}; shift
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 WLS=${@:-c3 c2}
 cd $GRAFT_REPO_ROOT
+export RAYN_HIP_ENV_TUNING=1   # the library reads RAYN_HIP_WORKERS / _COLD_BYTES / ... only under this opt-in (include/rayn_hip.h)
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 timeout 900 python tools/fuzz_parity.py 150 5000 2>&1 | tail -4

@@ -6,7 +6,7 @@ import numpy as np, torch, rayn_amd
 from rayn_amd import setup as S
 from bench import WORKLOADS
 scene, W, H, samples, bounces, desc = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
-cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb}[scene]((W, H))
+cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
 p = rayn_amd.frame_params(W, H, samples, bounces)
 tabs = rayn_amd.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W, H)
 ctx = rayn_amd.Context(0); ctx.upload_world(w.to_desc(cam))

@@ -8,7 +8,7 @@ from rayn_amd import setup as S
 from bench import WORKLOADS
 N = int(sys.argv[1]); wl = sys.argv[2] if len(sys.argv) > 2 else "c3"
 scene, W, H, samples, bounces, desc = WORKLOADS[wl]
-cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb}[scene]((W, H))
+cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
 tabs = rayn_amd.build_tables(4 * samples, bounces, 2, 1, W, H)
 ctx = rayn_amd.Context(0); ctx.upload_world(w.to_desc(cam))
 d = [torch.from_numpy(t).cuda() for t in tabs]
