@@ -28,6 +28,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+def usable_cpus():
+    """CPUs this process may actually use: min(visible CPUs, scheduler affinity, cgroup quota).  The GPU boxes show 256 hardware threads
+    but run the container under cpu.max = 16 CPUs (measured, profiles/r04_exp_workers_cold_cpu.txt: the oracle peaks at 16 threads and
+    loses a third of its rate at 256) - rounds 1-3 reported `cores: 256` for what were 16."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def kernel_source_hash():
     """sha256 over the kernel sources, the shared math header and the build flags: PMC traffic files under profiles/ are
     stamped with it, so a stale file is detected."""
@@ -316,7 +342,7 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import oracle_py as O
-        threads = os.cpu_count() or 1
+        threads = usable_cpus()  # what the container may use (cgroup quota), not the host's thread count
         # The oracle runs a tile serially on one thread (like the reference).  A 16x16 tile of this workload is about a minute
         # of one core at 1024 spp, so the CPU sample uses smaller tiles (a legal Film::render_frame_into tile_size) that hold
         # <= 4096 paths each: same scene, resolution, spp, bounces and per-path work, bounded wall time and a balanced thread
@@ -339,7 +365,7 @@ def main():
             t_w = time.perf_counter()
             _, ctr_w = O.render(wd, p, tabs, threads=threads)
             t_w = time.perf_counter() - t_w
-            cpu_baseline = {"value": round(ctr_w.paths / t_w / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
+            cpu_baseline = {"value": round(ctr_w.paths / t_w / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "host_threads_visible": os.cpu_count(), "kind": "port",
                             "tile": [p.tile_w, p.tile_h], "gpu_tile": [p.tile_w, p.tile_h], "frame_ms": round(t_w * 1e3, 1),
                             "sample": f"the WHOLE frame ({ctr_w.tiles} tiles of {p.tile_w}x{p.tile_h} pixels = the GPU's own tiles and packet grouping, {ctr_w.paths} paths, "
                                       f"{ctr_w.segments} segments), C++ oracle (restatement of rayn's CPU path; rayn itself cannot be built here), "
@@ -349,7 +375,7 @@ def main():
             rounds = int(min(32, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))
             k = int(min(n_tiles, threads * rounds))
             t_cpu, paths_cpu, k_used = run(k)
-            cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "kind": "port",
+            cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "host_threads_visible": os.cpu_count(), "kind": "port",
                             "tile": [ct, ct], "gpu_tile": [p.tile_w, p.tile_h],
                             "sample": f"{k_used} of {n_tiles} {ct}x{ct}-pixel tiles (evenly spread, {paths_cpu} paths) of the same workload, C++ oracle "
                                       f"(restatement of rayn's CPU path; rayn itself cannot be built here), {t_cpu:.1f} s; the GPU renders "

@@ -18,8 +18,11 @@ OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(HERE, "rayn.patch")
 EDITS = {}
 
 
+GROUP = ["hip"]  # the group the following edit() calls belong to: "hip" (the backend binding), "dump" (RAYN_DUMP only), "both"
+
+
 def edit(path, old, new, count=1):
-    EDITS.setdefault(path, []).append((old, new, count))
+    EDITS.setdefault(path, []).append((old, new, count, GROUP[0]))
 
 
 # ---- src/main.rs: the three new modules + an opt-in switch next to the CPU call -------------------------------------
@@ -624,6 +627,7 @@ edit("src/film.rs", """    channels: Mutex<GenericArray<ChannelStorage, N>>,
     pub(crate) res: Extent2u,
 }
 """)
+GROUP[0] = "both"
 edit("src/filter.rs", """pub struct FilterImportanceSampler {
     inverse_cdf: [f32; FILTER_TABLE_SIZE],
 }
@@ -632,6 +636,7 @@ edit("src/filter.rs", """pub struct FilterImportanceSampler {
 }
 """)
 
+GROUP[0] = "dump"
 # ---- RAYN_DUMP=<dir>[,<tile>]: the observable state of one render in tools/rayn_dump.py's format (N2, INTEGRATION.md 4a) -------
 # src/dump.rs is a NEW file carried by the patch; src/film.rs writes through it, src/hitable.rs exposes the bin lengths.
 NEW_FILES = {}
@@ -839,22 +844,31 @@ edit("src/film.rs", """                    spawned_wrays.push(wray);
 """)
 
 
-def main():
+def generate(groups, out):
+    """unified diff of the reference's src/ with the edits of `groups` applied"""
     tmp = tempfile.mkdtemp(prefix="rayn_patch_")
     try:
         for side in ("a", "b"):
             os.makedirs(os.path.join(tmp, side))
             shutil.copytree(os.path.join(REF, "src"), os.path.join(tmp, side, "src"))
+        n_files = 0
         for path, edits in EDITS.items():
             f = os.path.join(tmp, "b", path)
             text = open(f).read()
-            for old, new, count in edits:
+            touched = False
+            for old, new, count, group in edits:
+                if group not in groups and group != "both":
+                    continue
                 assert text.count(old) == count, f"{path}: expected {count} occurrence(s) of {old!r}, found {text.count(old)}"
                 text = text.replace(old, new)
+                touched = True
+            n_files += touched
             open(f, "w").write(text)
-        for path, text in NEW_FILES.items():
-            assert not os.path.exists(os.path.join(tmp, "a", path)), path
-            open(os.path.join(tmp, "b", path), "w").write(text)
+        if "dump" in groups:
+            for path, text in NEW_FILES.items():
+                assert not os.path.exists(os.path.join(tmp, "a", path)), path
+                open(os.path.join(tmp, "b", path), "w").write(text)
+                n_files += 1
         r = subprocess.run(["diff", "-ruN", "a/src", "b/src"], cwd=tmp, capture_output=True, text=True)
         assert r.returncode == 1, r.stderr
         # drop diff's timestamps: the patch should not change from run to run
@@ -867,10 +881,17 @@ def main():
                 if ln.startswith("--- a/") and ln[6:].strip() in NEW_FILES:
                     ln = "--- /dev/null\n"  # a file the patch creates (git apply wants the null source)
             lines.append(ln)
-        open(OUT, "w").write("".join(lines))
-        print(f"wrote {OUT}: {len(lines)} lines, {len(EDITS)} files")
+        open(out, "w").write("".join(lines))
+        print(f"wrote {out}: {len(lines)} lines, {n_files} files")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    # rayn.patch: everything (the HIP backend binding + the dump hooks).  rayn_dump.patch: ONLY the RAYN_DUMP hooks - what
+    # tools/pin_against_rayn.sh applies to pin the CPU oracle against an unmodified rayn: no GPU, no librayn_hip.so to link.
+    generate(("hip", "dump"), OUT)
+    generate(("dump",), os.path.join(os.path.dirname(OUT), "rayn_dump.patch") if len(sys.argv) <= 2 else OUT.replace(".patch", "_dump.patch"))
 
 
 if __name__ == "__main__":

@@ -26,12 +26,24 @@ def build(force=False):
 _libs = {}
 
 
-def lib(fma=False):
-    name = "librayn_oracle_fma.so" if fma else "librayn_oracle.so"
+VARIANTS = ("minmax_swapped", "minmax_ieee", "libm", "normalize_div", "dot_plain", "normals_central", "normals_order", "lerp_alt")
+
+
+def build_variants():
+    """The alternative-reading libraries of oracle/Makefile `variants` (oracle/SENSITIVITY.md); never used by the parity tests."""
+    subprocess.check_call(["make", "-C", _HERE, "-j4", "variants"], stdout=subprocess.DEVNULL)
+
+
+def lib(fma=False, variant=None):
+    """The oracle library: default (unfused mul_add), fma=True (fused), or variant=<name of VARIANTS> = ONE assumption of the
+    header's list read the other way (sensitivity analysis / naming a wrong assumption when pinning against rayn)."""
+    if variant is not None:
+        assert variant in VARIANTS and not fma, variant
+    name = f"librayn_oracle_{variant}.so" if variant else ("librayn_oracle_fma.so" if fma else "librayn_oracle.so")
     if name not in _libs:
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
-            build()
+            build_variants() if variant else build()
         L = C.CDLL(path)
         fp = C.POINTER(C.c_float)
         up = C.POINTER(C.c_uint32)
@@ -60,9 +72,9 @@ def _up(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
-def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter_kind=0, filter_radius=1.5, fma=False, filter_params=(0.0, 0.0)):
+def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter_kind=0, filter_radius=1.5, fma=False, filter_params=(0.0, 0.0), variant=None):
     """Samples::new_rd + per-pixel scramble + FilterImportanceSampler::new, oracle versions."""
-    L = lib(fma)
+    L = lib(fma, variant)
     n1 = L.oracle_sets_1d(max_bounces, volume_marches)
     n2 = L.oracle_sets_2d(max_bounces, volume_marches)
     s1 = np.zeros(spp * n1, np.float32)
@@ -75,9 +87,9 @@ def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter_
     return s1, s2, scr, fis
 
 
-def render(world_desc, params, tables, threads=None, tile_subset=None, fma=False):
+def render(world_desc, params, tables, threads=None, tile_subset=None, fma=False, variant=None):
     """Film::render_frame_into on the CPU.  Returns (film dict, Counters)."""
-    L = lib(fma)
+    L = lib(fma, variant)
     s1, s2, scr, fis = tables
     n = params.width * params.height
     color = np.zeros((n, 3), np.float32)
@@ -100,9 +112,9 @@ def render(world_desc, params, tables, threads=None, tile_subset=None, fma=False
             "normal": normal.reshape(h, w, 3)}, ctr
 
 
-def trace_tile(world_desc, params, tables, tile_index, fma=False):
+def trace_tile(world_desc, params, tables, tile_index, fma=False, variant=None):
     """Per-depth packet lanes of one tile in process_hits order: dict of uint32 arrays."""
-    L = lib(fma)
+    L = lib(fma, variant)
     s1, s2, scr, fis = tables
     cap = (params.tile_w * params.tile_h * params.samples * 4 + 64) * (params.max_bounces + 2)
     arrs = [np.zeros(cap, np.uint32) for _ in range(6)]

@@ -109,9 +109,9 @@ struct Tables {
                             const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles, \
                             const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const uint32_t* tile_cls_base, const DCtl* ctl); \
     void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq, \
-                      uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, DCtl* ctl, \
+                      uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, unsigned long long* alive_mask, uint8_t* bgrp_cnt, DCtl* ctl, \
                       unsigned long long* evals, ShadeHooks hooks, const Tuning& tun);              \
-    void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile, \
+    void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const unsigned long long* alive_mask, const uint32_t* grp_base, const uint32_t* grp_tile, \
                                 const uint32_t* tile_out_base, uint32_t max_slots, uint32_t* qn, uint32_t n_tiles, const uint32_t* tile_total, \
                                 const DCtl* ctl);                                                   \
     void launch_unpack_tiles(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha, \

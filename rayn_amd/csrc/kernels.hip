@@ -342,27 +342,41 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
 constexpr uint32_t QUEUE_UNROLL = 4; // groups a wave of a queue-streaming kernel has in flight per trip
 
 // per-group object histogram of the extend results (input of the bin scan)
+// inclusive prefix sum inside every row of 16 lanes (DPP row shifts, no LDS): lane 15 of a row ends up with the row's total
+RD uint32_t row_scan16(uint32_t n) {
+    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x111, 0xF, 0xF, true); // row_shr:1
+    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x112, 0xF, 0xF, true); // row_shr:2
+    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x114, 0xF, 0xF, true); // row_shr:4
+    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x118, 0xF, 0xF, true); // row_shr:8
+    return n;
+}
 __global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8_t* __restrict__ ent_obj, const DCtl* __restrict__ ctl,
                                                      uint8_t* __restrict__ grp_cnt) {
-    // These streaming kernels are LATENCY-bound when a wave has one load in flight (r1: 0.5 TB/s): every wave takes QUEUE_UNROLL
-    // consecutive-in-stride groups per trip and issues all their loads before using any.
-    const uint32_t n_entries = ctl->q_groups << 6, lane = lane_id();
+    // r4: every lane takes FOUR consecutive entries (one dword), so a wave's load covers four 64-entry groups (256 B instead of the
+    // 64 B of a byte per lane: the byte version was latency-bound at 0.8 TB/s with eight such loads in flight) and a row of 16 lanes
+    // is one group.  Per class: the bytes equal to c are found with an exact zero-byte test on v ^ (c * 0x01010101), counted per
+    // lane (v_bcnt) and summed over the row with four DPP adds - no ballots, no scalar work.  Lane 15 of each row packs the group's
+    // 16 class counts into 16 bytes and stores them with one 128-bit store.
+    const uint32_t n_dw = ctl->q_groups << 4; // dwords of object bytes (n_entries is a multiple of 64)
+    const uint32_t* __restrict__ obj4 = (const uint32_t*)ent_obj;
     const uint32_t stride = gridDim.x * blockDim.x;
-    constexpr uint32_t HIST_UNROLL = 8; // one byte load per group: keep more of them in flight
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_entries; i0 += stride * HIST_UNROLL) { // whole waves: n_entries % 64 == 0
-        uint32_t obj[HIST_UNROLL];
+    constexpr uint32_t HIST_UNROLL = 4;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_dw; i0 += stride * HIST_UNROLL) { // rows of 16 lanes are in or out together
+        uint32_t v[HIST_UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < HIST_UNROLL; u++) { const uint32_t i = i0 + u * stride; obj[u] = ent_obj[i < n_entries ? i : 0u]; if (i >= n_entries) obj[u] = OBJ_NONE; }
+        for (uint32_t u = 0; u < HIST_UNROLL; u++) { const uint32_t i = i0 + u * stride; v[u] = i < n_dw ? obj4[i] : 0xFFFFFFFFu; }
 #pragma unroll
         for (uint32_t u = 0; u < HIST_UNROLL; u++) {
             const uint32_t i = i0 + u * stride;
-            if (i >= n_entries) break; // wave-uniform
-            uint32_t mine = 0;
+            uint32_t acc[4] = {0u, 0u, 0u, 0u};
             for (uint32_t c = 0; c < nclass; c++) {
-                const uint32_t cnt = (uint32_t)__popcll(__ballot(obj[u] == c));
-                if (lane == c) mine = cnt;
+                const uint32_t x = v[u] ^ (c * 0x01010101u);
+                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); // 0x80 in every byte of x that is zero (exact)
+                const uint32_t n = row_scan16((uint32_t)__popc(z));
+                const uint32_t sh = n << (8u * (c & 3u));
+                if ((c >> 2) == 0) acc[0] |= sh; else if ((c >> 2) == 1) acc[1] |= sh; else if ((c >> 2) == 2) acc[2] |= sh; else acc[3] |= sh;
             }
-            if (lane < nclass) grp_cnt[(i >> 6) * SCAN_NC_BIN + lane] = (uint8_t)mine; // one store of nclass bytes per group
+            if (i < n_dw && (threadIdx.x & 15u) == 15u) *(uint4*)(grp_cnt + (size_t)(i >> 4) * SCAN_NC_BIN) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
 }
@@ -537,7 +551,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(uint32_t nclass, const uint
             const bool in = i < n_entries;
             obj[u] = in ? ent_obj[i] : OBJ_NONE;
             ref[u] = in ? q[i] : INVALID;
-            tbase[u] = in ? grp_tile[i >> 6] : 0u;
+            tbase[u] = grp_tile[__builtin_amdgcn_readfirstlane((int)(in ? i >> 6 : 0u))]; // per group = wave-uniform: a scalar load
         }
 #pragma unroll
         for (uint32_t u = 0; u < QUEUE_UNROLL; u++) { // second wave: the two dependent lookups
@@ -560,7 +574,9 @@ __global__ void __launch_bounds__(256) k_bin_scatter(uint32_t nclass, const uint
 }
 
 // stable compaction of the survivors of a shade pass into the next ray queue (a26)
-__global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restrict__ bq, const uint8_t* __restrict__ alive,
+// (survivor flags arrive as ONE 64-bit ballot per 64-slot group, written by k_shade_setup: an eighth of the bytes of a flag per slot,
+// and the rank inside the group is mbcnt of that mask - no per-slot byte load, no ballot here)
+__global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restrict__ bq, const unsigned long long* __restrict__ alive_mask,
                                                           const uint32_t* __restrict__ grp_base, const uint32_t* __restrict__ grp_tile,
                                                           const uint32_t* __restrict__ tile_out_base, const DCtl* __restrict__ ctl,
                                                           uint32_t* __restrict__ qn, uint32_t n_tiles, const uint32_t* __restrict__ tile_total) {
@@ -570,21 +586,25 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j0 = blockIdx.x * blockDim.x + threadIdx.x; j0 < n_slots; j0 += stride * QUEUE_UNROLL) {
         uint32_t a[QUEUE_UNROLL], ref[QUEUE_UNROLL], tbase[QUEUE_UNROLL], gbase[QUEUE_UNROLL];
+        unsigned long long am[QUEUE_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
             const uint32_t j = j0 + u * stride;
-            const bool in = j < n_slots;
-            a[u] = in ? alive[j] : 0u;
+            const bool in = j < n_slots; // wave-uniform: a wave's 64 slots are one group
+            // everything that is per GROUP is wave-uniform: survivor mask, tile, output base -> scalar loads; one vector load (bq) per slot
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(in ? j >> 6 : 0u));
+            am[u] = in ? alive_mask[g] : 0ull;
+            a[u] = (uint32_t)(am[u] >> (j & 63u)) & 1u;
             ref[u] = in ? bq[j] : INVALID;
-            tbase[u] = in ? grp_tile[j >> 6] : 0u;
-            gbase[u] = in ? grp_base[j >> 6] : 0u;
+            tbase[u] = grp_tile[g];
+            gbase[u] = grp_base[g];
         }
 #pragma unroll
-        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) tbase[u] = a[u] ? tile_out_base[tbase[u]] : 0u;
+        for (uint32_t u = 0; u < QUEUE_UNROLL; u++) tbase[u] = tile_out_base[__builtin_amdgcn_readfirstlane((int)tbase[u])];
 #pragma unroll
         for (uint32_t u = 0; u < QUEUE_UNROLL; u++) {
             if (j0 + u * stride >= n_slots) break; // wave-uniform
-            const uint32_t rank = mbcnt(__ballot(a[u] != 0));
+            const uint32_t rank = mbcnt(am[u]);
             if (a[u]) qn[tbase[u] + gbase[u] + rank] = ref[u];
         }
     }
@@ -613,7 +633,7 @@ constexpr int SETUP_WAVES = 6; // waves per SIMD the register budget of k_shade_
 template <bool COUNT>
 __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* __restrict__ scp, Tables tab, const float* __restrict__ scramble,
                                                       uint32_t depth, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl, Pool pool, Nee nee,
-                                                      uint8_t* __restrict__ alive, uint8_t* __restrict__ bgrp_cnt,
+                                                      unsigned long long* __restrict__ alive_mask, uint8_t* __restrict__ bgrp_cnt,
                                                       unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
@@ -844,9 +864,8 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
         }
         nee.flags[j] = (uint8_t)(flags | (is_alive ? 1u : 0u));
     }
-    alive[j] = is_alive ? 1 : 0;
-    uint64_t m = __ballot(is_alive);
-    if (lane == 0) bgrp_cnt[j >> 6] = (uint8_t)__popcll(m);
+    const uint64_t m = __ballot(is_alive); // the group's survivors: count for the repack scan, mask for the scatter's ranks
+    if (lane == 0) { alive_mask[j >> 6] = m; bgrp_cnt[j >> 6] = (uint8_t)__popcll(m); }
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
@@ -1801,7 +1820,7 @@ void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, 
     else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
 }
 void launch_group_hist(hipStream_t s, uint32_t nclass, const uint8_t* ent_obj, uint32_t max_entries, const DCtl* ctl, uint8_t* grp_cnt) {
-    hipLaunchKernelGGL(k_group_hist, stride_grid(max_entries, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, ent_obj, ctl, grp_cnt);
+    hipLaunchKernelGGL(k_group_hist, stride_grid(max_entries / 4, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, ent_obj, ctl, grp_cnt);
 }
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
                       const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
@@ -1821,13 +1840,13 @@ void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const
                        n_tiles, tile_cls_cnt, tile_total, tile_cls_base);
 }
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
-                  uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, uint8_t* alive, uint8_t* bgrp_cnt, DCtl* ctl,
+                  uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, unsigned long long* alive_mask, uint8_t* bgrp_cnt, DCtl* ctl,
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
     hooks.before(0);
     const uint32_t shmem = ns > 4 ? VOL_MEMO_LIGHTS * 3 * 256 * 4 : 0; // ns > 4: the volume scatters (volume NEE samples exist)
     const dim3 sgrid = grid_for(max_slots, 256);
-    if (count) hipLaunchKernelGGL(k_shade_setup<true>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, evals + 1);
-    else hipLaunchKernelGGL(k_shade_setup<false>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive, bgrp_cnt, evals + 1);
+    if (count) hipLaunchKernelGGL(k_shade_setup<true>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive_mask, bgrp_cnt, evals + 1);
+    else hipLaunchKernelGGL(k_shade_setup<false>, sgrid, dim3(256), shmem, s, sc, tab, scramble, depth, bq, ctl, pool, nee, alive_mask, bgrp_cnt, evals + 1);
     hooks.after(0);
     if (has_sdf) {
         hooks.before(1);
@@ -1844,10 +1863,10 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
     hipLaunchKernelGGL(k_shade_finish, stride_grid(max_slots, 256, STREAM_BLOCKS), dim3(256), 0, s, sc, bq, ctl, pool, nee);
     hooks.after(2);
 }
-void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const uint8_t* alive, const uint32_t* grp_base, const uint32_t* grp_tile,
+void launch_compact_scatter(hipStream_t s, const uint32_t* bq, const unsigned long long* alive_mask, const uint32_t* grp_base, const uint32_t* grp_tile,
                             const uint32_t* tile_out_base, uint32_t max_slots, uint32_t* qn, uint32_t n_tiles, const uint32_t* tile_total,
                             const DCtl* ctl) {
-    hipLaunchKernelGGL(k_compact_scatter, stride_grid(max_slots, 256, STREAM_BLOCKS), dim3(256), 0, s, bq, alive, grp_base, grp_tile, tile_out_base, ctl, qn, n_tiles, tile_total);
+    hipLaunchKernelGGL(k_compact_scatter, stride_grid(max_slots, 256, STREAM_BLOCKS), dim3(256), 0, s, bq, alive_mask, grp_base, grp_tile, tile_out_base, ctl, qn, n_tiles, tile_total);
 }
 void launch_unpack_tiles(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t width, float* color, float* alpha, float* background,
                          float* normal, const float* packed, size_t packed_pixels) {

@@ -46,7 +46,8 @@ namespace {
 // tiles are dealt to two workers so that one worker's HBM-bound kernels, queue-size readbacks and kernel
 // tails run underneath the other's VALU-bound march kernels (measured: +6 % on config 2).
 struct Worker {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the stream this worker's frame share runs on: the CALLER's stream for worker 0, `own` for the others
+    hipStream_t own = nullptr;             // created on first use by workers >= 1 (every further stream of a process costs 12-17 ms, the first ~100 ms)
     Arena arena;
     uint32_t* h_totals = nullptr;          // pinned
     DCtl* h_ctl = nullptr;                 // pinned: the control block read back once per frame share
@@ -79,6 +80,7 @@ struct rayn_ctx {
     bool profiling = false, counting = false;
     size_t batch_paths = (size_t)1 << 28;   // per worker; also limited by the HBM budget and the 32-bit job refs (render_device)
     size_t two_worker_min_paths = (size_t)1 << 22;
+    size_t small_share_paths = (size_t)1 << 27; // single-batch shares up to this size are split between two co-resident workers (render_device)
     size_t cold_bytes = (size_t)44 << 30;   // arena bytes (all workers together) of a context's FIRST frame (render_device); 0 = full size at once
     uint64_t frames_rendered = 0;
     float* host_stage = nullptr; size_t host_stage_cap = 0; // rayn_hip_render_frame: device copies of the caller's tables + film (grow-only)
@@ -251,13 +253,16 @@ hipEvent_t get_event(Worker* w) {
     return e;
 }
 
-// stream, control block, counters, pinned read-back buffers and the 'done' event of a worker, created on first use
-int ensure_worker(rayn_ctx* ctx, Worker* w) {
-    if (w->stream) return RAYN_OK;
-    const bool ok = hipSetDevice(ctx->device) == hipSuccess && hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess &&
-                    hipMalloc((void**)&w->d_evals, 32) == hipSuccess && hipMalloc((void**)&w->d_ctl, sizeof(DCtl)) == hipSuccess &&
-                    hipHostMalloc((void**)&w->h_totals, 16) == hipSuccess && hipHostMalloc((void**)&w->h_ctl, sizeof(DCtl)) == hipSuccess &&
-                    hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess;
+// control block, counters, pinned read-back buffers and the 'done' event of a worker (+ its own stream for workers >= 1), created on
+// first use.  Worker 0 runs on the caller's stream: a single-worker frame - every small frame, e.g. the reference's shipped 1280x720x8spp
+// - needs no stream of its own and no cross-stream fork / join (measured: a second hipStreamCreate costs 12-17 ms of a cold 62 ms frame).
+int ensure_worker(rayn_ctx* ctx, Worker* w, bool own_stream) {
+    bool ok = hipSetDevice(ctx->device) == hipSuccess;
+    if (ok && !w->d_ctl)
+        ok = hipMalloc((void**)&w->d_evals, 32) == hipSuccess && hipMalloc((void**)&w->d_ctl, sizeof(DCtl)) == hipSuccess &&
+             hipHostMalloc((void**)&w->h_totals, 16) == hipSuccess && hipHostMalloc((void**)&w->h_ctl, sizeof(DCtl)) == hipSuccess &&
+             hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess;
+    if (ok && own_stream && !w->own) ok = hipStreamCreateWithFlags(&w->own, hipStreamNonBlocking) == hipSuccess;
     return ok ? RAYN_OK : fail(ctx, RAYN_ERR_HIP, std::string("worker resources: ") + hipGetErrorString(hipGetLastError()));
 }
 
@@ -334,7 +339,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     // ---- device memory: one arena carved for the largest batch of a plan
     struct Layout {
         size_t CAP = 0, QCAP = 0, BCAP = 0, JOBCAP = 0;
-        Pool pool; uint32_t *q, *qn, *bq; uint8_t *ent_obj, *alive;
+        Pool pool; uint32_t *q, *qn, *bq; uint8_t* ent_obj; unsigned long long* alive;
         uint8_t* grp_cnt; uint32_t *grp_base, *grp_tile; uint8_t* bgrp_cnt; uint32_t *bgrp_base, *bgrp_tile;
         DTile* d_all_tiles; uint32_t* pgrp_tile;
         uint32_t *tgbA, *tgcA, *tgbB, *tgcB, *tile_total, *tile_valid, *tile_out_base, *tile_cls_cnt, *tile_cls_base;
@@ -352,7 +357,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
         pool.geo0 = A.take<float4>(CAP); pool.geo1 = A.take<float4>(CAP); pool.col0 = A.take<float4>(CAP); pool.col1 = A.take<float4>(CAP);
         pool.aov = A.take<float4>(CAP); pool.term_key = A.take<uint32_t>(CAP); pool.term_info = A.take<uint8_t>(CAP);
         L->q = A.take<uint32_t>(QCAP); L->qn = A.take<uint32_t>(QCAP); L->bq = A.take<uint32_t>(BCAP);
-        L->ent_obj = A.take<uint8_t>(QCAP); L->alive = A.take<uint8_t>(BCAP);
+        L->ent_obj = A.take<uint8_t>(QCAP); L->alive = A.take<unsigned long long>(BG); // survivor ballot of every binned 64-slot group
         L->grp_cnt = A.take<uint8_t>(QG * SCAN_NC_BIN); L->grp_base = A.take<uint32_t>(QG * SCAN_NC_BIN); L->grp_tile = A.take<uint32_t>(QG);
         L->bgrp_cnt = A.take<uint8_t>(BG); L->bgrp_base = A.take<uint32_t>(BG); L->bgrp_tile = A.take<uint32_t>(BG);
         L->d_all_tiles = A.take<DTile>(total_tiles); L->pgrp_tile = A.take<uint32_t>(CAP / 64 + 1);
@@ -407,7 +412,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     for (size_t bi = 0; bi < plan.batches.size(); bi++) {
         std::vector<BatchTile>& batch = plan.batches[bi];
         Pool& pool = L.pool; Nee& nee = L.nee;
-        uint32_t *q = L.q, *qn = L.qn, *bq = L.bq; uint8_t *ent_obj = L.ent_obj, *alive = L.alive;
+        uint32_t *q = L.q, *qn = L.qn, *bq = L.bq; uint8_t* ent_obj = L.ent_obj; unsigned long long* alive = L.alive;
         uint8_t* grp_cnt = L.grp_cnt; uint32_t *grp_base = L.grp_base, *grp_tile = L.grp_tile;
         uint8_t* bgrp_cnt = L.bgrp_cnt; uint32_t *bgrp_base = L.bgrp_base, *bgrp_tile = L.bgrp_tile;
         uint32_t *pgrp_tile = L.pgrp_tile, *tgbA = L.tgbA, *tgcA = L.tgcA, *tgbB = L.tgbB, *tgcB = L.tgcB;
@@ -606,17 +611,30 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
             // (config 3, 651 B per path: one worker with 2^28-path batches beats two with 2^27; config 2, 331 B: both fit)
             const size_t first1 = first == ~(size_t)0 ? first : first * (size_t)c; // what ONE worker would get of the first-frame budget
             const size_t solo = std::max<size_t>(4096, std::min(first1, std::min(std::min(ctx->batch_paths, index_cap), budget_paths)));
-            if (c == 1 || (owned_paths >= ctx->two_worker_min_paths && owned_paths >= (size_t)c * cap && 4 * cap >= 3 * solo) ||
+            // r4: a share that fits ONE batch of a single worker (a rank's eighth of config 2, the reference's shipped 7.4 M-path frame)
+            // is split between TWO workers all the same: their persistent march kernels are co-resident, so the tail of one worker's
+            // launch (a few long rays; 0.1-0.3 ms per launch) runs under the other worker's kernels.  Measured
+            // (profiles/r04_exp_workers_cold_cpu.txt): 1/8 of c2 86.1 -> 84.1 ms, the shipped frame 36.5 -> 35.2 ms; three or four
+            // workers, or half-size persistent grids, are slower.
+            // (not on the FIRST frame of a context: the second worker's stream alone costs 12-17 ms to create - more than the split gains on a
+            // frame this small - and a host that renders one frame per process, the reference's own usage, would only ever pay)
+            const bool small_share = c == 2 && ctx->frames_rendered > 0 && owned_paths >= ctx->two_worker_min_paths && owned_paths <= solo &&
+                                     owned_paths <= ctx->small_share_paths;
+            if (c == 1 || small_share || (owned_paths >= ctx->two_worker_min_paths && owned_paths >= (size_t)c * cap && 4 * cap >= 3 * solo) ||
                 (ctx->two_worker_min_paths == 0)) { nw = c; F.batch_paths = cap; break; }
         }
     }
     std::vector<BatchTile> share[MAX_WORKERS];
     for (size_t i = 0; i < owned.size(); i++) share[i % nw].push_back(owned[i]);
-    for (int i = 0; i < nw; i++) { rc = ensure_worker(ctx, &ctx->workers[i]); if (rc) return rc; }
+    for (int i = 0; i < nw; i++) {
+        rc = ensure_worker(ctx, &ctx->workers[i], i > 0);
+        if (rc) return rc;
+        ctx->workers[i].stream = i == 0 ? stream : ctx->workers[i].own;
+    }
     // fork: the worker streams start after everything already queued on the caller's stream
     HIPCHK(hipEventRecord(ctx->ev_fork, stream));
     HIPCHK(hipStreamSynchronize(stream)); // F.hs is on this stack frame: make sure the scene copy has been consumed
-    for (int i = 0; i < nw; i++) HIPCHK(hipStreamWaitEvent(ctx->workers[i].stream, ctx->ev_fork, 0));
+    for (int i = 1; i < nw; i++) HIPCHK(hipStreamWaitEvent(ctx->workers[i].stream, ctx->ev_fork, 0));
     {
         std::vector<std::thread> threads;
         for (int i = 1; i < nw; i++) threads.emplace_back([&, i]() { run_worker(ctx, &ctx->workers[i], F, share[i]); });
@@ -627,7 +645,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     for (int i = 0; i < nw; i++) {
         Worker& w = ctx->workers[i];
         if (w.rc) return fail(ctx, w.rc, w.err);
-        if (!share[i].empty()) HIPCHK(hipStreamWaitEvent(stream, w.done, 0));
+        if (i > 0 && !share[i].empty()) HIPCHK(hipStreamWaitEvent(stream, w.done, 0));
         ctx->stats.paths += w.stats.paths; ctx->stats.segments += w.stats.segments; ctx->stats.shaded_slots += w.stats.shaded_slots;
         ctx->stats.tiles += w.stats.tiles; ctx->stats.batches += w.stats.batches;
         ctx->stats.launches_extend += w.stats.launches_extend; ctx->stats.launches_shade += w.stats.launches_shade;
@@ -888,7 +906,7 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
     if (ctx->gather_tiles) (void)hipFree(ctx->gather_tiles);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Worker& w : ctx->workers) {
-        if (w.stream) (void)hipStreamSynchronize(w.stream);
+        if (w.own) (void)hipStreamSynchronize(w.own);
         for (auto e : w.event_pool) (void)hipEventDestroy(e);
         if (w.d_ctl) (void)hipFree(w.d_ctl);
         if (w.arena.base) (void)hipFree(w.arena.base);
@@ -896,7 +914,7 @@ void rayn_hip_destroy(rayn_ctx* ctx) {
         if (w.h_totals) (void)hipHostFree(w.h_totals);
         if (w.h_ctl) (void)hipHostFree(w.h_ctl);
         if (w.done) (void)hipEventDestroy(w.done);
-        if (w.stream) (void)hipStreamDestroy(w.stream);
+        if (w.own) (void)hipStreamDestroy(w.own);
     }
     if (ctx->d_rec) (void)hipFree(ctx->d_rec);
     if (ctx->host_stage) (void)hipFree(ctx->host_stage);

@@ -286,3 +286,28 @@ def test_a_rayn_side_dump_is_accepted_by_the_comparer(tmp_path):
     json.dump(rayn_manifest, open(b / "manifest.json", "w"))
     r = subprocess.run([sys.executable, tool, "compare", str(a), str(b)], capture_output=True, text=True)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
+@needs_reference
+def test_dump_only_patch_applies_alone_and_is_current(tmp_path):
+    """bindings/rayn_dump.patch = ONLY the RAYN_DUMP hooks (what tools/pin_against_rayn.sh applies: pinning the CPU oracle needs no GPU
+    library): it applies to a pristine copy of the reference on its own, leaves `mod hip` / `describe()` out, and is what
+    bindings/make_patch.py regenerates."""
+    d = tmp_path / "rayn"
+    shutil.copytree(os.path.join(REFERENCE, "src"), d / "src")
+    subprocess.run(["git", "init", "-q", "."], cwd=d, check=True)
+    patch = os.path.join(ROOT, "bindings", "rayn_dump.patch")
+    r = subprocess.run(["git", "apply", "--check", "-p1", patch], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    subprocess.run(["git", "apply", "-p1", patch], cwd=d, check=True)
+    main = (d / "src" / "main.rs").read_text()
+    assert "mod dump;" in main and "mod hip;" not in main and "RAYN_HIP" not in main
+    assert (d / "src" / "dump.rs").exists() and "fn describe" not in (d / "src" / "hitable.rs").read_text()
+    assert "bin_lens" in (d / "src" / "hitable.rs").read_text() and "crate::dump::write_u32" in (d / "src" / "film.rs").read_text()
+    out = tmp_path / "regen.patch"
+    subprocess.run([sys.executable, os.path.join(ROOT, "bindings", "make_patch.py"), REFERENCE, str(out)], check=True, capture_output=True)
+    assert (tmp_path / "regen_dump.patch").read_text() == open(patch).read(), "bindings/rayn_dump.patch is stale: run bindings/make_patch.py"
+    # the one-command pin script exists, is executable and refers to this patch and to the comparer
+    sh = os.path.join(ROOT, "tools", "pin_against_rayn.sh")
+    text = open(sh).read()
+    assert os.access(sh, os.X_OK) and "rayn_dump.patch" in text and "rayn_dump.py" in text and "cargo" in text

@@ -3,7 +3,13 @@
 section 8c "Net", row N2): the only route to ever pin this project's oracle against REAL rayn.
 
   python tools/rayn_dump.py dump OUT_DIR [--scene s2 --w 64 --h 64 --samples 2 --bounces 3 --tile 1 --backend oracle|gpu]
+                                         [--fma 1] [--variant NAME] [--tables-from DIR]
   python tools/rayn_dump.py compare DIR_A DIR_B
+
+  --scene ship = the reference's setup::setup() as shipped; --fma 1 = the fused-mul_add oracle (rayn built with +fma);
+  --variant NAME = one assumption of the oracle read the other way (oracle/SENSITIVITY.md, oracle_py.VARIANTS);
+  --tables-from DIR = take samples_1d / samples_2d / scramble / fis from another dump (rayn's own): a film that still differs then
+  is not the tables' fault (assumptions A6 / A7 are out of the picture).
 
 A dump is a directory of raw little-endian arrays + manifest.json:
   samples_1d.f32   Samples::samples_1d  (spp * sets_1d)            src/sampler.rs:11-15
@@ -33,17 +39,23 @@ def dump(args):
     from common import case
     from oracle import oracle_py as O
     wd, p = case(args.scene, args.w, args.h, args.samples, args.bounces)
-    tabs = O.build_tables(4 * args.samples, args.bounces, p.volume_marches, p.frame, args.w, args.h)
+    fma, variant = bool(args.fma), args.variant
+    tabs = O.build_tables(4 * args.samples, args.bounces, p.volume_marches, p.frame, args.w, args.h, fma=fma, variant=variant)
+    if args.tables_from:
+        theirs = tuple(np.fromfile(os.path.join(args.tables_from, k + ".f32"), np.float32) for k in F32[:4])
+        assert all(a.shape == b.shape for a, b in zip(theirs, tabs)), "table sizes differ: other spp / bounce count / resolution?"
+        tabs = theirs
     if args.backend == "gpu":
         import rayn_amd
         ctx = rayn_amd.Context(0)
         ctx.upload_world(wd)
+        ctx.set_fma_policy(int(fma))
         ctx.set_trace_tile(args.tile)
         film = ctx.render_host(p, tabs)
         trace = ctx.trace()
     else:
-        film, _ = O.render(wd, p, tabs)
-        trace = O.trace_tile(wd, p, tabs, args.tile)
+        film, _ = O.render(wd, p, tabs, fma=fma, variant=variant)
+        trace = O.trace_tile(wd, p, tabs, args.tile, fma=fma, variant=variant)
     os.makedirs(args.out, exist_ok=True)
     arrays = dict(zip(F32[:4], tabs))
     arrays.update({k: film[k] for k in ("color", "alpha", "background", "normal")})
@@ -53,7 +65,8 @@ def dump(args):
     tr.tofile(os.path.join(args.out, "trace.u32"))
     json.dump({"scene": args.scene, "width": args.w, "height": args.h, "SAMPLES": args.samples, "spp": 4 * args.samples,
                "max_bounces": args.bounces, "volume_marches": p.volume_marches, "frame": p.frame, "time_range": [p.time_start, p.time_end],
-               "tile": [p.tile_w, p.tile_h], "trace_tile": args.tile, "backend": args.backend}, open(os.path.join(args.out, "manifest.json"), "w"), indent=1)
+               "tile": [p.tile_w, p.tile_h], "trace_tile": args.tile, "backend": args.backend,
+               "fma": int(fma), "variant": variant, "tables_from": args.tables_from}, open(os.path.join(args.out, "manifest.json"), "w"), indent=1)
     print(f"wrote {args.out}: {len(arrays) + 1} arrays")
 
 
@@ -99,6 +112,9 @@ def main():
     d.add_argument("--bounces", type=int, default=3)
     d.add_argument("--tile", type=int, default=1)
     d.add_argument("--backend", default="oracle", choices=["oracle", "gpu"])
+    d.add_argument("--fma", type=int, default=0, choices=[0, 1])
+    d.add_argument("--variant", default=None)
+    d.add_argument("--tables-from", default=None)
     c = sub.add_parser("compare")
     c.add_argument("a")
     c.add_argument("b")
