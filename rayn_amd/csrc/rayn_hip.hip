@@ -515,9 +515,9 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
         if (c.overflow) return wfail(w, RAYN_ERR_HIP, c.overflow & 1u ? "internal: binned queue overflow" : "internal: ray queue overflow");
         w->stats.segments = c.segments; w->stats.shaded_slots = c.shaded_slots; w->stats.shadow_jobs = c.shadow_jobs;
         // algorithmic HBM bytes of the queue stages: bin = hist 1 B/entry + scatter q 4 + ent_obj 1 per entry, bq 4 per slot,
-        // ~85 B of scan bookkeeping per group; repack = bq 4 + alive 1 per slot, q' 4 per survivor slot, ~9 B per group
+        // ~85 B of scan bookkeeping per group; repack = bq 4 per slot, q' 4 per survivor slot, 17 B per group (survivor ballot 8, count 1, base 4, tile 4)
         w->stats.queue_bytes_bin = c.entries_sum * 6 + c.shaded_slots * 4 + (c.entries_sum / 64) * 85;
-        w->stats.queue_bytes_compact = c.shaded_slots * 5 + c.next_sum * 4 + (c.shaded_slots / 64) * 9;
+        w->stats.queue_bytes_compact = c.shaded_slots * 4 + c.next_sum * 4 + (c.shaded_slots / 64) * 17;
     }
     if (count) WCHK(hipMemcpy(w->evals, w->d_evals, 24, hipMemcpyDeviceToHost));
     return 0;

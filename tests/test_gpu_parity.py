@@ -472,6 +472,14 @@ def _custom_world(kind, res):
         world.hitables.push(R.TracedSDF(R.MandelBox(7, R.BoxFold(1.0), R.SphereFold(0.5, 1.0), -2.0, scale_vel=-3.0), 1,
                                         R.Linear(R.vec3(0.3, 0.0, 0.0), R.vec3(0.0, 2.0, 0.0))))
         world.hitables[1].sdf.scale_vel = 2.5
+    elif kind == "full_house":  # RAYN_MAX_HITABLES = 16 objects: every class of the bin histogram / scan / scatter is populated (ids 0..15)
+        mats = [world.materials.add_material(R.Lambertian(R.Srgb(0.8, 0.3, 0.2))), world.materials.add_material(R.Dielectric.new_remap(R.Srgb(0.3, 0.6, 0.3), 0.4)),
+                world.materials.add_material(R.Emissive.new_splat(R.Srgb(2.0, 1.5, 1.0)))]
+        k = 0
+        while len(world.hitables) < 16:
+            a = 0.7 * k
+            world.hitables.push(R.Sphere(R.vec3(1.9 * np.cos(a), -1.1 + 0.25 * k, 1.9 * np.sin(a)), 0.22 + 0.02 * k, mats[k % 3]))
+            k += 1
     elif kind == "lambert_sdf_sphere":
         world.hitables[1] = R.TracedSDF(R.SphereSDF(1.0), world.materials.add_material(R.Lambertian(R.Srgb(0.5, 0.5, 0.5))))
     else:
@@ -480,7 +488,7 @@ def _custom_world(kind, res):
 
 
 @pytest.mark.parametrize("kind", ["thinlens", "thinlens_volume", "ortho", "anim_pinhole", "anim_thinlens", "anim_spheres", "lambertian", "no_lights", "spheres_only", "two_sdfs", "lambert_sdf_sphere",
-                                  "offset_sdf", "moving_sdf", "moving_two_sdfs", "moving_bulb", "morphing_box", "morphing_two_sdfs"])
+                                  "offset_sdf", "moving_sdf", "moving_two_sdfs", "moving_bulb", "morphing_box", "morphing_two_sdfs", "full_house"])
 def test_closed_set_parity(gpu_ctx, oracle, kind):
     from rayn_amd import params as P
     w, h, samples, bounces = 40, 32, 2, 4

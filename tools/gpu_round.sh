@@ -48,7 +48,14 @@ timeout 600 python tools/share_profile.py 0 1 bulb 2>&1 | tail -1 | sed 's/^/bul
 timeout 600 python tools/host_rate.py c3 2>&1 | tail -1
 timeout 600 python tools/host_rate.py c2 2>&1 | tail -1
 timeout 600 python bench.py --workload c4 --steps 1 --warmup 1 --no-roofline --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/${R}_bench_c4_$TAG.json; cat gpurun_out/${R}_bench_c4_$TAG.json | cut -c1-200
+if [ -n "$WHOLE_C5" ]; then  # 136 G paths, ~3 GPU-minutes: only on request (r3's number stands, the march kernels did not change in r4)
 timeout 900 python bench.py --workload c5 --steps 1 --warmup 0 --no-roofline --no-cold --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/${R}_bench_c5_$TAG.json; cat gpurun_out/${R}_bench_c5_$TAG.json | cut -c1-200
+fi
+# the reference's own workload (src/main.rs:47-82): bench line with cold_ms, whole-frame 16x16 CPU leg; what an 8-GPU launch waits for
+timeout 600 python bench.py --workload shipped 2>&1 | tail -1 > gpurun_out/${R}_bench_shipped_$TAG.json; cut -c1-400 gpurun_out/${R}_bench_shipped_$TAG.json
+timeout 600 python tools/share_balance.py 8 c2 2>&1 | tail -1
+timeout 600 python tools/share_balance.py 8 c3 2>&1 | tail -1
+for i in 1 2 3; do timeout 120 python tools/cold_breakdown.py shipped 0 2>&1 | tail -1; done
 # the reference's own usage: one frame per process, back to back (tools/cold_frame.py)
 sleep 6
-for WL in c3 c3 c2 c2; do timeout 300 python tools/cold_frame.py $WL -1 0 2>&1 | tail -1; done
+for WL in c3 c2 c2 shipped shipped; do timeout 300 python tools/cold_frame.py $WL -1 0 2>&1 | tail -1; done
