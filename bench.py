@@ -161,8 +161,9 @@ def main():
         ctx.render_host(p, tabs)
         cold_ms = (time.perf_counter() - t_cold) * 1e3
         cold_detail = {"context_ms": round((t_created - t_cold) * 1e3, 1), "first_frame_ms": round(cold_ms - (t_created - t_cold) * 1e3, 1),
-                       "note": "context_ms = rayn_hip_create (HIP runtime start-up of this process included) + upload_world; first_frame_ms = "
-                               "rayn_hip_render_frame on host buffers (tables up, arenas allocated, code objects loaded, film down)"}
+                       "note": "context_ms = rayn_hip_create + upload_world in THIS process, whose HIP runtime torch has already started (hipInit, 56-71 ms, is "
+                               "not in it; the first queue, 85-104 ms, is); first_frame_ms = rayn_hip_render_frame on host buffers (tables up, arenas allocated, "
+                               "code objects loaded, film down).  A torch-less host (tools/cold_frame.py) pays 200-244 ms from process start for the shipped workload"}
     d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
     film = rayn_amd.film.alloc_device_film(W, H, device)
     gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo"), force=args.force_dist) if use_dist else None
