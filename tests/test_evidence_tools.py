@@ -54,3 +54,22 @@ def test_committed_pmc_files_match_the_kernel_sources():
             pytest.skip(f"profiles/r04_pmc_hbm_{wl}.json was measured on other kernel sources: re-run tools/gpu_round.sh before the round ends")
         dom = j["kernels"]["k_shadow1" if wl == "c3" else "k_extend1"]
         assert dom["hbm_bytes_per_launch"] > 0 and 0.2 < dom["valu_inst_per_cycle_simd"] <= 0.5 and 0.5 < dom["lanes_enabled"] <= 1.0
+
+
+def test_usable_cpus_respects_the_cgroup_quota(monkeypatch, tmp_path):
+    """bench.py's CPU leg runs on the CPUs the container may USE (the GPU boxes show 256 threads under a 16-CPU quota)."""
+    sys.path.insert(0, ROOT)
+    import builtins
+    import bench
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("200000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert bench.usable_cpus() == min(2, os.cpu_count() or 1)
