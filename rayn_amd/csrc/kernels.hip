@@ -339,48 +339,48 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
 }
 
-constexpr uint32_t QUEUE_UNROLL = 4; // groups a wave of a queue-streaming kernel has in flight per trip
+constexpr uint32_t QUEUE_UNROLL = 8; // groups a wave of a queue-streaming kernel has in flight per trip (r4: 4 -> 8, bin -3 %, repack -3 %)
 
 // per-group object histogram of the extend results (input of the bin scan)
-// inclusive prefix sum inside every row of 16 lanes (DPP row shifts, no LDS): lane 15 of a row ends up with the row's total
-RD uint32_t row_scan16(uint32_t n) {
-    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x111, 0xF, 0xF, true); // row_shr:1
-    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x112, 0xF, 0xF, true); // row_shr:2
-    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x114, 0xF, 0xF, true); // row_shr:4
-    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x118, 0xF, 0xF, true); // row_shr:8
+// sum over every quad of 4 lanes (two DPP quad-permute butterflies, no LDS): all four lanes end up with the quad's total
+RD uint32_t quad_total(uint32_t n) {
+    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0xB1, 0xF, 0xF, true); // quad_perm:[1,0,3,2]
+    n += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x4E, 0xF, 0xF, true); // quad_perm:[2,3,0,1]
     return n;
+}
+RD uint32_t count_eq4(uint32_t v, uint32_t pat) {
+    const uint32_t x = v ^ pat;
+    return (uint32_t)__popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu)); // bytes of v equal to the class byte (exact zero-byte test)
 }
 __global__ void __launch_bounds__(256) k_group_hist(uint32_t nclass, const uint8_t* __restrict__ ent_obj, const DCtl* __restrict__ ctl,
                                                      uint8_t* __restrict__ grp_cnt) {
-    // r4: every lane takes FOUR consecutive entries (one dword), so a wave's load covers four 64-entry groups (256 B instead of the
-    // 64 B of a byte per lane: the byte version was latency-bound at 0.8 TB/s with eight such loads in flight) and a row of 16 lanes
-    // is one group.  Per class: the bytes equal to c are found with an exact zero-byte test on v ^ (c * 0x01010101), counted per
-    // lane (v_bcnt) and summed over the row with four DPP adds - no ballots, no scalar work.  Lane 15 of each row packs the group's
-    // 16 class counts into 16 bytes and stores them with one 128-bit store.
-    const uint32_t n_dw = ctl->q_groups << 4; // dwords of object bytes (n_entries is a multiple of 64)
-    const uint32_t* __restrict__ obj4 = (const uint32_t*)ent_obj;
+    // r4: every lane takes SIXTEEN consecutive entries (one 128-bit load), so a quad of lanes is one 64-entry group and a wave's load covers
+    // 16 groups (1 KB instead of the 64 B of a byte per lane: the byte version was latency-bound at 0.8 TB/s with eight such loads in
+    // flight).  Per class: the bytes equal to c are found with an exact zero-byte test on v ^ (c * 0x01010101), counted per lane (v_bcnt)
+    // and summed over the quad with two DPP adds - no ballots, no scalar work.  Lane 3 of each quad packs the group's 16 class counts
+    // into 16 bytes and stores them with one 128-bit store.  (A dword per lane with a 16-lane DPP row scan was 6 % slower.)
+    const uint32_t n_q = ctl->q_groups << 2; // 16-byte pieces of the object bytes (n_entries is a multiple of 64)
+    const uint4* __restrict__ obj16 = (const uint4*)ent_obj;
     const uint32_t stride = gridDim.x * blockDim.x;
-    constexpr uint32_t HIST_UNROLL = 4;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_dw; i0 += stride * HIST_UNROLL) { // rows of 16 lanes are in or out together
-        uint32_t v[HIST_UNROLL];
+    constexpr uint32_t HIST_UNROLL = 2;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_q; i0 += stride * HIST_UNROLL) { // quads are in or out together
+        uint4 v[HIST_UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < HIST_UNROLL; u++) { const uint32_t i = i0 + u * stride; v[u] = i < n_dw ? obj4[i] : 0xFFFFFFFFu; }
+        for (uint32_t u = 0; u < HIST_UNROLL; u++) { const uint32_t i = i0 + u * stride; v[u] = i < n_q ? obj16[i] : make_uint4(~0u, ~0u, ~0u, ~0u); }
 #pragma unroll
         for (uint32_t u = 0; u < HIST_UNROLL; u++) {
             const uint32_t i = i0 + u * stride;
             uint32_t acc[4] = {0u, 0u, 0u, 0u};
             for (uint32_t c = 0; c < nclass; c++) {
-                const uint32_t x = v[u] ^ (c * 0x01010101u);
-                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); // 0x80 in every byte of x that is zero (exact)
-                const uint32_t n = row_scan16((uint32_t)__popc(z));
+                const uint32_t pat = c * 0x01010101u;
+                const uint32_t n = quad_total(count_eq4(v[u].x, pat) + count_eq4(v[u].y, pat) + count_eq4(v[u].z, pat) + count_eq4(v[u].w, pat));
                 const uint32_t sh = n << (8u * (c & 3u));
                 if ((c >> 2) == 0) acc[0] |= sh; else if ((c >> 2) == 1) acc[1] |= sh; else if ((c >> 2) == 2) acc[2] |= sh; else acc[3] |= sh;
             }
-            if (i < n_dw && (threadIdx.x & 15u) == 15u) *(uint4*)(grp_cnt + (size_t)(i >> 4) * SCAN_NC_BIN) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            if (i < n_q && (threadIdx.x & 3u) == 3u) *(uint4*)(grp_cnt + (size_t)(i >> 2) * SCAN_NC_BIN) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
 }
-
 // ------------------------------------------------------------------------------------------------
 // a14 (bins) / a26 (repack): per-tile stable offsets.  One block per tile walks the tile's groups
 // and turns per-group class counts into tile-relative output bases:
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint32_t* __restr
             const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(in ? j >> 6 : 0u));
             am[u] = in ? alive_mask[g] : 0ull;
             a[u] = (uint32_t)(am[u] >> (j & 63u)) & 1u;
-            ref[u] = in ? bq[j] : INVALID;
+            ref[u] = in ? bq[j] : INVALID; // (loading survivors only - a load that waits for the mask - was 50 % SLOWER: the scalar mask load then sits in front of every vector load)
             tbase[u] = grp_tile[g];
             gbase[u] = grp_base[g];
         }
@@ -1820,7 +1820,7 @@ void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, 
     else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
 }
 void launch_group_hist(hipStream_t s, uint32_t nclass, const uint8_t* ent_obj, uint32_t max_entries, const DCtl* ctl, uint8_t* grp_cnt) {
-    hipLaunchKernelGGL(k_group_hist, stride_grid(max_entries / 4, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, ent_obj, ctl, grp_cnt);
+    hipLaunchKernelGGL(k_group_hist, stride_grid(max_entries / 16, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, ent_obj, ctl, grp_cnt);
 }
 void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t stride, uint32_t pad, const uint8_t* grp_cnt,
                       const uint32_t* tgb, const uint32_t* tgc, uint32_t* grp_base, uint32_t* grp_tile, uint32_t* tile_total,
