@@ -113,12 +113,6 @@ RD float packet_time(const DScene& sc, const uint32_t* __restrict__ q, const Poo
 // index, so the fetch order never influences the output.
 constexpr uint32_t CHUNK = 256;
 constexpr uint32_t ENDGAME_ENTRIES = 256 * 32 * 64; // about one ray per resident lane of the chip
-// r4: a wave's FIRST chunk is static - wave w of the launch takes entries [w * CHUNK, (w + 1) * CHUNK) - and only the later ones come from
-// the shared counter (offset by the statically dealt range).  All 8 192 waves of a persistent launch asking ONE address for their first
-// chunk at the same moment is ~86 us at the ~95 atomics per us a single address takes: nothing on a 85 ms launch, 2 % of a rank's share
-// of config 2 or of the reference's shipped frame, whose launches last a few ms.  (Which wave marches which ray never shows in the result.)
-RD uint32_t wave_of_launch() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
-RD uint32_t static_range() { return gridDim.x * (blockDim.x >> 6) * CHUNK; }
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, uint32_t depth, const uint32_t* __restrict__ q,
@@ -131,8 +125,8 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
     const Thr th = make_thr(sc, depth);
     const uint32_t nh = sc.n_hitables;
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
-    uint32_t cur = min(wave_of_launch() * CHUNK, n_entries), end = min(cur + CHUNK, n_entries); // wave-uniform chunk window; the first one is static
-    bool exhausted = cur == end; // nothing dealt statically = nothing left in the counter's range either
+    uint32_t cur = 0, end = 0; // wave-uniform chunk window
+    bool exhausted = false;
     // per-lane ray state
     bool has = false, first = false, nan = false;
     uint32_t ent = 0, P = 0, k = 0, id = OBJ_NONE, m = 0, evals = 0, sbits = 0;
@@ -166,7 +160,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
                 if (cur == end) {
                     if (exhausted) break;
                     uint32_t base = 0;
-                    if (lane == 0) base = static_range() + atomicAdd(head, CHUNK);
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n_entries) { exhausted = true; break; }
                     cur = base;
@@ -245,8 +239,8 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     const uint32_t nh = sc.n_hitables, max_marches = sc.max_marches;
     const DHitable h = sc.h[ks]; // uniform copy
     const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
-    uint32_t cur = min(wave_of_launch() * CHUNK, n_entries), end = min(cur + CHUNK, n_entries); // the first chunk is static (see CHUNK)
-    bool exhausted = cur == end, endgame = n_entries - cur < ENDGAME_ENTRIES;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false, endgame = false;
     // current ray
     bool c_has = false, first = false, nan = false;
     uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0, evals = 0;
@@ -269,7 +263,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
                 if (need == 0) break;
                 if (cur == end) {
                     uint32_t base = 0;
-                    if (lane == 0) base = static_range() + atomicAdd(head, CHUNK);
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n_entries) { exhausted = true; break; }
                     cur = base;
@@ -949,8 +943,8 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
     uint32_t* const head = &ctl->head_shadow;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
-    uint32_t cur = min(wave_of_launch() * CHUNK, n_jobs), end = min(cur + CHUNK, n_jobs); // the first chunk is static (see CHUNK)
-    bool exhausted = cur == end;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
     bool has = false, first = false, nan = false;
     uint32_t ref = 0, k = 0, m = 0, evals = 0;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, wa = f3{0, 0, 0}, wb = f3{0, 0, 0};
@@ -975,7 +969,7 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
                 if (need == 0) break;
                 if (cur == end) {
                     uint32_t base = 0;
-                    if (lane == 0) base = static_range() + atomicAdd(head, CHUNK);
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n_jobs) { exhausted = true; break; }
                     cur = base;
@@ -1034,8 +1028,8 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->shadow_jobs += n_jobs;
     const DHitable h = sc.h[ks];
     const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
-    uint32_t cur = min(wave_of_launch() * CHUNK, n_jobs), end = min(cur + CHUNK, n_jobs); // the first chunk is static (see CHUNK)
-    bool exhausted = cur == end, endgame = n_jobs - cur < ENDGAME_ENTRIES;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false, endgame = false;
     bool c_has = false, first = false, nan = false, n_has = false;
     uint32_t ref = 0, n_ref = 0, m = 0, evals = 0;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
@@ -1052,7 +1046,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                 if (need == 0) break;
                 if (cur == end) {
                     uint32_t base = 0;
-                    if (lane == 0) base = static_range() + atomicAdd(head, CHUNK);
+                    if (lane == 0) base = atomicAdd(head, CHUNK);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n_jobs) { exhausted = true; break; }
                     cur = base;
