@@ -104,7 +104,7 @@ struct Tables {
                           uint32_t* tile_valid, uint32_t* tile_cls_cnt, const DCtl* ctl);           \
     void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base, \
                             uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt, \
-                            uint32_t* tile_cls_base, uint32_t cap_groups);                          \
+                            uint32_t* tile_cls_base, uint32_t cap_groups, uint32_t* base_hist);     \
     void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base, \
                             const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles, \
                             const uint32_t* tile_cls_cnt, const uint32_t* tile_total, const uint32_t* tile_cls_base, const DCtl* ctl); \
@@ -118,7 +118,7 @@ struct Tables {
                              float* background, float* normal, const float* packed, size_t packed_pixels); \
     void launch_batch_setup(hipStream_t s, const DTile* tiles, uint32_t n_tiles, uint32_t* pgrp_tile, uint32_t* tgb, uint32_t* tgc); \
     void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool, \
-                        float* out_color, float* out_alpha, float* out_background, float* out_normal); \
+                        float* out_color, float* out_alpha, float* out_background, float* out_normal, const uint32_t* base_hist, uint32_t hist_stride); \
     void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n); \
     void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n); \
     void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n); \

@@ -448,7 +448,8 @@ __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const ui
                                                        const uint32_t* __restrict__ tile_valid, uint32_t* __restrict__ tile_out_base,
                                                        uint32_t* __restrict__ out_grp_begin, uint32_t* __restrict__ out_grp_count,
                                                        DCtl* __restrict__ ctl, int stage, uint32_t nclass, uint32_t pad,
-                                                       const uint32_t* __restrict__ tile_cls_cnt, uint32_t* __restrict__ tile_cls_base, uint32_t cap_groups) {
+                                                       const uint32_t* __restrict__ tile_cls_cnt, uint32_t* __restrict__ tile_cls_base, uint32_t cap_groups,
+                                                       uint32_t* __restrict__ base_hist) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_vsum[16];
     __shared__ uint32_t s_run, s_valid;
@@ -483,6 +484,7 @@ __global__ void __launch_bounds__(1024) k_tile_prefix(uint32_t n_tiles, const ui
             out_grp_begin[k] = begin;
             out_grp_count[k] = groups;
             tile_out_base[k] = begin * 64u;
+            if (base_hist) base_hist[k] = begin * 64u; // bin stage: where the tile's binned segment starts at THIS depth (kept for the film resolve's 32-bit keys)
             uint32_t off = begin * 64u; // where each class bin of the tile starts (bins padded to 'pad' slots)
             for (uint32_t c = 0; c < nclass; c++) {
                 tile_cls_base[k * SCAN_NC_BIN + c] = off;
@@ -1249,14 +1251,30 @@ RD bool is_sorted_reg(const K (&key)[KPL]) {
     return __ballot(!ok) == 0;
 }
 
+// serial float sum of src[lo .. hi) in index order; 128-bit LDS reads once the index is 4-aligned (one LDS instruction per four terms:
+// the serial-sum phase is ISSUE-bound - a handful of lanes, one instruction per 4 cycles - so instructions per term are what it costs)
+RD float serial_sum_range(const float* src, uint32_t lo, uint32_t hi) {
+    float a = 0.0f;
+    uint32_t e = lo;
+    for (; e < hi && (e & 3u); e++) a += src[e];
+    for (; e + 8 <= hi; e += 8) {
+        const float4 v0 = *(const float4*)(src + e), v1 = *(const float4*)(src + e + 4);
+        a += v0.x; a += v0.y; a += v0.z; a += v0.w;
+        a += v1.x; a += v1.y; a += v1.z; a += v1.w;
+    }
+    for (; e < hi; e++) a += src[e];
+    return a;
+}
+
 template <uint32_t KPL>
 __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
                                                      float* __restrict__ out_color, float* __restrict__ out_alpha,
                                                      float* __restrict__ out_background, float* __restrict__ out_normal) {
     constexpr uint32_t n_sort = 64 * KPL;
-    __shared__ __attribute__((aligned(16))) float2 rg[n_sort]; // sorted samples: (r, g) | AOV pass: normal (x, y)
-    __shared__ __attribute__((aligned(16))) float2 bf[n_sort]; // (b, background flag)   | AOV pass: first half = normal z
-    float* nz = (float*)bf;
+    // r4: the sorted samples are staged CHANNEL-major (R | G | B, then normal x | y | z) + one flag byte, so that a serial-sum lane reads four
+    // terms with one 128-bit LDS instruction (see serial_sum_range and k_resolve_blk: this phase is bound by instruction issue)
+    __shared__ __attribute__((aligned(16))) float ch[3][n_sort];
+    __shared__ uint8_t s_flag[n_sort];
     constexpr unsigned long long NOKEY = ~0ull;
     const DScene& sc = *scp;
     const DTile tile = tiles[blockIdx.y];
@@ -1281,40 +1299,39 @@ __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ s
     }
     const bool sorted = is_sorted_reg<unsigned long long, KPL>(key); // sky-only pixels arrive sorted (sample-major layout)
     if (!sorted) bitonic_sort_reg<unsigned long long, KPL>(key);   // now element lane * KPL + r
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, nb = 0;
 #pragma unroll
-    for (uint32_t r = 0; r < KPL; r++) cnt += (uint32_t)__popcll(__ballot(key[r] != NOKEY));
+    for (uint32_t r = 0; r < KPL; r++) {
+        cnt += (uint32_t)__popcll(__ballot(key[r] != NOKEY));
+        nb += (uint32_t)__popcll(__ballot(key[r] != NOKEY && (((uint32_t)key[r] >> 12) & 1u)));
+    }
+    // Background samples are emitted at depth 0 only, i.e. they sort first: when they are exactly the first nb entries (always, unless
+    // max_bounces == 0 puts Color samples at depth 0 too) the two accumulators are plain serial sums over [0, nb) and [nb, cnt)
+    bool prefix_ok = true;
 #pragma unroll
     for (uint32_t r = 0; r < KPL; r++) {
         if (key[r] != NOKEY) {
             const uint32_t e = sorted ? r * 64 + lane : lane * KPL + r, lo = (uint32_t)key[r];
             const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
-            rg[e] = make_float2(c.x, c.y);
-            bf[e] = make_float2(c.z, __uint_as_float((lo >> 12) & 1u));
+            const uint32_t bg = (lo >> 12) & 1u;
+            ch[0][e] = c.x; ch[1][e] = c.y; ch[2][e] = c.z;
+            s_flag[e] = (uint8_t)bg;
+            prefix_ok = prefix_ok && (bg != 0) == (e < nb);
         }
     }
+    const bool split = __ballot(!prefix_ok) == 0;
     __syncthreads();
-    if (lane < 3) {
-        const float* src = lane < 2 ? (const float*)rg + lane : (const float*)bf; // stride 2 floats
-        const uint32_t* flg = (const uint32_t*)bf + 1;
-        float c = 0.0f, b = 0.0f;
-        uint32_t e = 0;
-        for (; e + 8 <= cnt; e += 8) {
-            float v[8];
-            uint32_t f[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) {
-                // two INDEPENDENT serial chains: the accumulator a sample does not belong to adds +0.0, an exact identity here
-                // (x + 0.0 == x for every x except -0.0, and a sum that starts at +0.0 never becomes -0.0 under round-to-nearest)
-                const bool bg = f[u] != 0;
-                c += bg ? 0.0f : v[u];
-                b += bg ? v[u] : 0.0f;
-            }
+    if (split) {
+        if (lane < 6) { // lanes 0..2: Color r, g, b over [nb, cnt); lanes 3..5: Background over [0, nb)
+            const uint32_t c = lane % 3u, isb = lane / 3u;
+            const float v = serial_sum_range(ch[c], isb ? 0u : nb, isb ? nb : cnt) / n;
+            if (isb) out_background[3 * fi + c] = v; else out_color[3 * fi + c] = v;
         }
-        for (; e < cnt; e++) {
-            if (flg[2 * e]) b += src[2 * e]; else c += src[2 * e];
+    } else if (lane < 3) { // general order: two independent serial chains with a flag test per term (the accumulator a sample does not
+        float c = 0.0f, b = 0.0f; // belong to is simply not touched)
+        for (uint32_t e = 0; e < cnt; e++) {
+            const float v = ch[lane][e];
+            if (s_flag[e]) b += v; else c += v;
         }
         out_color[3 * fi + lane] = c / n;
         out_background[3 * fi + lane] = b / n;
@@ -1339,14 +1356,12 @@ __global__ void __launch_bounds__(64) k_resolve_reg(const DScene* __restrict__ s
         if (k32[r] != INVALID) {
             const uint32_t e = sorted0 ? r * 64 + lane : lane * KPL + r;
             const float4 a = pool.aov[P0 + (k32[r] & 0xFFFFu)];
-            rg[e] = make_float2(a.x, a.y);
-            nz[e] = a.z;
+            ch[0][e] = a.x; ch[1][e] = a.y; ch[2][e] = a.z;
         }
     __syncthreads();
     // Alpha adds 1.0 per depth-0 surface sample: every partial sum is an integer < 2^24, so the serial sum is the count
     if (lane == 3) out_alpha[fi] = (float)cnt0 / n;
-    else if (lane < 2) out_normal[3 * fi + lane] = serial_sum((const float*)rg + lane, 2, cnt0) / n;
-    else if (lane == 2) out_normal[3 * fi + 2] = serial_sum(nz, 1, cnt0) / n;
+    else if (lane < 3) out_normal[3 * fi + lane] = serial_sum_range(ch[lane], 0u, cnt0) / n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1409,17 +1424,15 @@ RD void bitonic_sort_block4(K (&key)[KPL], K* exch /* [NT * KPL] */) {
 template <uint32_t NT, uint32_t KPL>
 __global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ scp, const DTile* __restrict__ tiles, Pool pool,
                                                      float* __restrict__ out_color, float* __restrict__ out_alpha,
-                                                     float* __restrict__ out_background, float* __restrict__ out_normal) {
+                                                     float* __restrict__ out_background, float* __restrict__ out_normal,
+                                                     const uint32_t* __restrict__ base_hist, uint32_t hist_stride) {
     constexpr uint32_t n_sort = NT * KPL; // 1024 (2 waves x 8 keys), 2048 (4 x 8) or 4096 (8 x 8)
-    // 16 B per sample: the sorted samples' (r, g) and (b, flag) for the serial-sum lanes; the sort's cross-wave exchange (u64 keys)
-    // and the sortedness check use the same memory before the staging starts
-    __shared__ __attribute__((aligned(16))) float2 rg[n_sort];
-    __shared__ __attribute__((aligned(16))) float2 bf[n_sort];
-    unsigned long long* exch64 = (unsigned long long*)rg; // [n_sort] u64 = rg
-    uint32_t* exch32 = (uint32_t*)rg;
-    float* nz = (float*)bf;
-    uint32_t* s_meta = (uint32_t*)bf; // [0] valid keys, [1] "some pair is out of order": only live between the key load and the sort (bf is staged later)
-    constexpr unsigned long long NOKEY = ~0ull;
+    // 13 B per sample: the sorted samples channel-major (R | G | B, then normal x | y | z) for the serial-sum lanes + one flag byte; the
+    // sort's cross-wave exchange, the sorted key array of the rank search and the sortedness check use the R plane before the staging starts
+    __shared__ __attribute__((aligned(16))) float ch[3][n_sort];
+    __shared__ uint8_t s_flag[n_sort];
+    __shared__ uint32_t s_meta[4]; // [0] valid keys, [1] "some pair is out of order", [2] Background samples, [3] "the Background samples are not a prefix of the order"
+    uint32_t* exch32 = (uint32_t*)ch[0];
     const DScene& sc = *scp;
     const DTile tile = tiles[blockIdx.y];
     const uint32_t lpix = blockIdx.x;
@@ -1428,63 +1441,89 @@ __global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ s
     const uint32_t P0 = tile.pool_base + lpix * spp;
     const size_t fi = film_pixel(tile, lpix, sc.width);
     const float n = (float)spp;
-    // ---- Color / Background in (depth, slot) order
-    unsigned long long key[KPL];
-    uint32_t mine = 0;
+    // ---- Color / Background in (depth, slot) order.  r4: the sort runs on 32-bit keys WITHOUT a payload - depth:7 | slot relative to
+    // where the tile's binned segment began at that depth (k_tile_prefix keeps those bases per depth; a tile's segment is < 2^23 slots for
+    // <= 1024 pixels x 4096 spp) - and every sample then finds its rank in the sorted key array by binary search (keys of a pixel are
+    // distinct: a slot holds one path).  Half the registers, one shuffle + v_cmp + v_cndmask per compare-exchange instead of two shuffles,
+    // a 64-bit compare and two selects.
+    constexpr uint32_t NOKEY = 0xFFFFFFFFu; // depth <= 120: no real key has the top bit set
+    uint32_t ko[KPL];
+    uint32_t mine = 0, bgm = 0;
 #pragma unroll
-    for (uint32_t r = 0; r < KPL; r++) { // sample-major: register r of thread t = sample r * 256 + t (coalesced)
+    for (uint32_t r = 0; r < KPL; r++) { // sample-major: register r of thread t = sample r * NT + t (coalesced)
         const uint32_t i = r * NT + tid;
-        unsigned long long k = NOKEY;
+        uint32_t k = NOKEY;
         if (i < spp) {
             const uint32_t info = pool.term_info[P0 + i];
-            if (info != TERM_NONE)
-                k = ((unsigned long long)(info & 0x7Fu) << 45) | ((unsigned long long)pool.term_key[P0 + i] << 13) | ((info >> 7) << 12) | i;
+            if (info != TERM_NONE) {
+                const uint32_t d = info & 0x7Fu;
+                k = (d << 23) | (pool.term_key[P0 + i] - base_hist[d * hist_stride + blockIdx.y]);
+                bgm |= (info >> 7) << r;
+            }
         }
-        key[r] = k;
+        ko[r] = k;
         mine += k != NOKEY;
-        exch64[i] = k;
+        exch32[i] = k;
     }
-    if (tid == 0) { s_meta[0] = 0; s_meta[1] = 0; }
+    if (tid < 4) s_meta[tid] = 0;
     __syncthreads();
     bool ok = true;
 #pragma unroll
-    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * NT + tid; ok = ok && (i + 1 >= n_sort || !(key[r] > exch64[i + 1])); }
+    for (uint32_t r = 0; r < KPL; r++) { const uint32_t i = r * NT + tid; ok = ok && (i + 1 >= n_sort || !(ko[r] > exch32[i + 1])); }
     if (mine) atomicAdd(&s_meta[0], mine);
+    if (bgm) atomicAdd(&s_meta[2], (uint32_t)__popc(bgm));
     if (!ok) s_meta[1] = 1;
     __syncthreads(); // also orders the LDS reads above before the exchange buffer is reused
-    const uint32_t cnt = s_meta[0];
+    const uint32_t cnt = s_meta[0], nb = s_meta[2];
     const bool sorted = s_meta[1] == 0;
-    if (!sorted) bitonic_sort_block4<unsigned long long, KPL, NT>(key, exch64); // now element tid * KPL + r
-    __syncthreads();
+    uint32_t rank[KPL];
 #pragma unroll
-    for (uint32_t r = 0; r < KPL; r++) {
-        if (key[r] != NOKEY) {
-            const uint32_t e = sorted ? r * NT + tid : tid * KPL + r, lo = (uint32_t)key[r];
-            const float4 c = pool.col0[P0 + (lo & 0xFFFu)];
-            rg[e] = make_float2(c.x, c.y);
-            bf[e] = make_float2(c.z, __uint_as_float((lo >> 12) & 1u));
+    for (uint32_t r = 0; r < KPL; r++) rank[r] = r * NT + tid; // already in order (sky-only pixels): a sample's rank is its index
+    if (!sorted) {
+        uint32_t ks[KPL];
+#pragma unroll
+        for (uint32_t r = 0; r < KPL; r++) ks[r] = ko[r];
+        bitonic_sort_block4<uint32_t, KPL, NT>(ks, exch32); // now element tid * KPL + r
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < KPL; r++) exch32[tid * KPL + r] = ks[r];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < KPL; r++) { // rank = number of sorted keys below this sample's key (branch-free lower bound, n_sort = 2^m)
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t step = n_sort / 2; step > 0; step >>= 1) pos += exch32[pos + step - 1] < ko[r] ? step : 0u;
+            rank[r] = pos;
         }
     }
-    __syncthreads();
-    if (tid < 3) {
-        const float* src = tid < 2 ? (const float*)rg + tid : (const float*)bf; // stride 2 floats
-        const uint32_t* flg = (const uint32_t*)bf + 1;
-        float c = 0.0f, b = 0.0f;
-        uint32_t e = 0;
-        for (; e + 8 <= cnt; e += 8) {
-            float v[8];
-            uint32_t f[8];
+    __syncthreads(); // every rank is known before the staging overwrites the key array
+    // Background samples are emitted at depth 0 only (src/integrator.rs:151-160), i.e. they sort first: when they are exactly the first nb
+    // entries of the order (always, unless max_bounces == 0 puts Color samples at depth 0 too) the two accumulators are two plain serial
+    // sums over [0, nb) and [nb, cnt) - no per-term flag test in the issue-bound loop
+    bool prefix_ok = true;
 #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) { v[u] = src[2 * (e + u)]; f[u] = flg[2 * (e + u)]; }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) { // two independent serial chains (see k_resolve_reg)
-                const bool bg = f[u] != 0;
-                c += bg ? 0.0f : v[u];
-                b += bg ? v[u] : 0.0f;
-            }
+    for (uint32_t r = 0; r < KPL; r++) {
+        if (ko[r] != NOKEY) {
+            const float4 c = pool.col0[P0 + r * NT + tid];
+            const uint32_t bg = (bgm >> r) & 1u;
+            ch[0][rank[r]] = c.x; ch[1][rank[r]] = c.y; ch[2][rank[r]] = c.z;
+            s_flag[rank[r]] = (uint8_t)bg;
+            prefix_ok = prefix_ok && (bg != 0) == (rank[r] < nb);
         }
-        for (; e < cnt; e++) {
-            if (flg[2 * e]) b += src[2 * e]; else c += src[2 * e];
+    }
+    if (!prefix_ok) s_meta[3] = 1;
+    __syncthreads();
+    if (s_meta[3] == 0) {
+        if (tid < 6) { // lanes 0..2: Color r, g, b over [nb, cnt); lanes 3..5: Background over [0, nb)
+            const uint32_t c = tid % 3u, isb = tid / 3u;
+            const float v = serial_sum_range(ch[c], isb ? 0u : nb, isb ? nb : cnt) / n;
+            if (isb) out_background[3 * fi + c] = v; else out_color[3 * fi + c] = v;
+        }
+    } else if (tid < 3) { // general order: two independent chains with a flag test per term (see k_resolve_reg)
+        float c = 0.0f, b = 0.0f;
+        for (uint32_t e = 0; e < cnt; e++) {
+            const float v = ch[tid][e];
+            if (s_flag[e]) b += v; else c += v;
         }
         out_color[3 * fi + tid] = c / n;
         out_background[3 * fi + tid] = b / n;
@@ -1502,7 +1541,7 @@ __global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ s
         mine += k != INVALID;
         exch32[i] = k;
     }
-    if (tid == 0) { s_meta[0] = 0; s_meta[1] = 0; }
+    if (tid < 2) s_meta[tid] = 0;
     __syncthreads();
     ok = true;
 #pragma unroll
@@ -1519,13 +1558,11 @@ __global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ s
         if (k32[r] != INVALID) {
             const uint32_t e = sorted0 ? r * NT + tid : tid * KPL + r;
             const float4 a = pool.aov[P0 + (k32[r] & 0xFFFFu)];
-            rg[e] = make_float2(a.x, a.y);
-            nz[e] = a.z;
+            ch[0][e] = a.x; ch[1][e] = a.y; ch[2][e] = a.z;
         }
     __syncthreads();
     if (tid == 3) out_alpha[fi] = (float)cnt0 / n;
-    else if (tid < 2) out_normal[3 * fi + tid] = serial_sum((const float*)rg + tid, 2, cnt0) / n;
-    else if (tid == 2) out_normal[3 * fi + 2] = serial_sum(nz, 1, cnt0) / n;
+    else if (tid < 3) out_normal[3 * fi + tid] = serial_sum_range(ch[tid], 0u, cnt0) / n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1829,9 +1866,9 @@ void launch_scan_tile(hipStream_t s, uint32_t n_tiles, uint32_t nclass, uint32_t
 }
 void launch_tile_prefix(hipStream_t s, uint32_t n_tiles, const uint32_t* tile_total, const uint32_t* tile_valid, uint32_t* tile_out_base,
                         uint32_t* ogb, uint32_t* ogc, DCtl* ctl, int stage, uint32_t nclass, uint32_t pad, const uint32_t* tile_cls_cnt,
-                        uint32_t* tile_cls_base, uint32_t cap_groups) {
+                        uint32_t* tile_cls_base, uint32_t cap_groups, uint32_t* base_hist) {
     hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, s, n_tiles, tile_total, tile_valid, tile_out_base, ogb, ogc, ctl, stage, nclass, pad, tile_cls_cnt,
-                       tile_cls_base, cap_groups);
+                       tile_cls_base, cap_groups, base_hist);
 }
 void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const uint8_t* ent_obj, const uint32_t* grp_base,
                         const uint32_t* grp_tile, const uint32_t* tile_out_base, uint32_t max_entries, uint32_t* bq, uint32_t n_tiles,
@@ -1875,19 +1912,19 @@ void launch_unpack_tiles(hipStream_t s, const DTile* tiles, uint32_t n_tiles, ui
     hipLaunchKernelGGL(k_unpack_tiles, dim3(n_tiles), dim3(256), 0, s, tiles, width, color, alpha, background, normal, pc, pa, pb, pn);
 }
 void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool,
-                    float* out_color, float* out_alpha, float* out_background, float* out_normal) {
+                    float* out_color, float* out_alpha, float* out_background, float* out_normal, const uint32_t* base_hist, uint32_t hist_stride) {
     const dim3 grid(max_tile_pixels, n_tiles);
     if (spp <= 1024) { // register-resident sort, one wave per pixel
         if (spp <= 64) hipLaunchKernelGGL(k_resolve_reg<1>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         else if (spp <= 128) hipLaunchKernelGGL(k_resolve_reg<2>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         else if (spp <= 256) hipLaunchKernelGGL(k_resolve_reg<4>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
         else if (spp <= 512) hipLaunchKernelGGL(k_resolve_reg<8>, grid, dim3(64), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
-        else hipLaunchKernelGGL((k_resolve_blk<128, 8>), grid, dim3(128), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal); // two waves per pixel
+        else hipLaunchKernelGGL((k_resolve_blk<128, 8>), grid, dim3(128), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal, base_hist, hist_stride); // two waves per pixel
         return;
     }
     if (spp <= 4096) { // four / eight waves per pixel, 8 keys per lane (config 5: 4096 spp)
-        if (spp <= 2048) hipLaunchKernelGGL((k_resolve_blk<256, 8>), grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
-        else hipLaunchKernelGGL((k_resolve_blk<512, 8>), grid, dim3(512), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal);
+        if (spp <= 2048) hipLaunchKernelGGL((k_resolve_blk<256, 8>), grid, dim3(256), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal, base_hist, hist_stride);
+        else hipLaunchKernelGGL((k_resolve_blk<512, 8>), grid, dim3(512), 0, s, sc, tiles, pool, out_color, out_alpha, out_background, out_normal, base_hist, hist_stride);
         return;
     }
     // 4096 < spp <= 16384 (the host rejects more): sixteen waves per pixel, 128 KB of dynamic LDS

@@ -343,6 +343,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
         uint8_t* grp_cnt; uint32_t *grp_base, *grp_tile; uint8_t* bgrp_cnt; uint32_t *bgrp_base, *bgrp_tile;
         DTile* d_all_tiles; uint32_t* pgrp_tile;
         uint32_t *tgbA, *tgcA, *tgbB, *tgcB, *tile_total, *tile_valid, *tile_out_base, *tile_cls_cnt, *tile_cls_base;
+        uint32_t* base_hist; size_t hist_stride; // [max_bounces + 1][max_tiles]: where each tile's binned segment began at every depth (film resolve keys)
         Nee nee;
     };
     // sizes (dry = true: only A.off advances) or carves the arena for batches of <= CAP pool slots in <= max_tiles tiles
@@ -365,6 +366,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
         L->tgbB = A.take<uint32_t>(max_tiles); L->tgcB = A.take<uint32_t>(max_tiles);
         L->tile_total = A.take<uint32_t>(max_tiles); L->tile_valid = A.take<uint32_t>(max_tiles); L->tile_out_base = A.take<uint32_t>(max_tiles);
         L->tile_cls_cnt = A.take<uint32_t>(max_tiles * SCAN_NC_BIN); L->tile_cls_base = A.take<uint32_t>(max_tiles * SCAN_NC_BIN);
+        L->hist_stride = max_tiles; L->base_hist = A.take<uint32_t>(((size_t)F.p->max_bounces + 1) * max_tiles);
         Nee& nee = L->nee;
         nee.cap = BCAP; nee.jobcap = JOBCAP;
         nee.x = A.take<float>(12 * BCAP); nee.vtr = A.take<float>((NS - 4 + 1) * BCAP); nee.pdf = A.take<float>(NS * BCAP); nee.aux = A.take<float>((NS - 4 + 1) * BCAP);
@@ -454,7 +456,8 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
                 Timed t(w, prof, PC_BIN);
                 K.group_hist(stream, hs.n_hitables, ent_obj, max_entries, d_ctl, grp_cnt); // timed with the bin stage it feeds (r1 / r2 timed it with the extend kernel)
                 K.scan_tile(stream, nt, hs.n_hitables, SCAN_NC_BIN, 4, grp_cnt, tgbA, tgcA, grp_base, grp_tile, tile_total, tile_valid, tile_cls_cnt, d_ctl);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0, hs.n_hitables, 4, tile_cls_cnt, tile_cls_base, (uint32_t)(BCAP / 64));
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbB, tgcB, d_ctl, 0, hs.n_hitables, 4, tile_cls_cnt, tile_cls_base, (uint32_t)(BCAP / 64),
+                              L.base_hist + (size_t)depth * L.hist_stride);
                 K.bin_scatter(stream, hs.n_hitables, qcur, ent_obj, grp_base, grp_tile, tile_out_base, max_entries, bq, nt, tile_cls_cnt, tile_total, tile_cls_base, d_ctl);
             }
             if (ctx->trace_tile >= 0) { // diagnostics only (synchronises): packet order of one tile, in HitStore::process_hits order
@@ -499,12 +502,12 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
             {
                 Timed t(w, prof, PC_COMPACT);
                 K.scan_tile(stream, nt, 1, 1, 1, bgrp_cnt, tgbB, tgcB, bgrp_base, bgrp_tile, tile_total, tile_valid, tile_cls_cnt, d_ctl);
-                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_ctl, 1, 1, 1, tile_cls_cnt, tile_cls_base, (uint32_t)(QCAP / 64));
+                K.tile_prefix(stream, nt, tile_total, tile_valid, tile_out_base, tgbA, tgcA, d_ctl, 1, 1, 1, tile_cls_cnt, tile_cls_base, (uint32_t)(QCAP / 64), nullptr);
                 K.compact_scatter(stream, bq, alive, bgrp_base, bgrp_tile, tile_out_base, max_slots, qnext, nt, tile_total, d_ctl);
             }
             std::swap(qcur, qnext);
         }
-        { Timed t(w, prof, PC_RESOLVE); K.resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, F.d_color, F.d_alpha, F.d_bg, F.d_normal); }
+        { Timed t(w, prof, PC_RESOLVE); K.resolve(stream, ctx->d_scene, d_tiles, nt, max_tile_pixels, spp, pool, F.d_color, F.d_alpha, F.d_bg, F.d_normal, L.base_hist, (uint32_t)L.hist_stride); }
     }
     WCHK(hipMemcpyAsync(w->h_ctl, d_ctl, sizeof(DCtl), hipMemcpyDeviceToHost, stream));
     WCHK(hipEventRecord(w->done, stream));
