@@ -197,6 +197,8 @@ FILM_CASES = [
     ("s3", 4, 2, 2048, 6, {"tile_size": (2, 2)}),    # 8192 spp, moving camera
     ("s2", 2, 2, 4096, 4, {"tile_size": (2, 2)}),    # 16384 spp (the supported maximum), volume
     ("s1", 2, 2, 2048, 0, {"tile_size": (2, 2)}),    # 8192 spp, depth 0 only: the keys arrive sorted (the resolve's no-sort path)
+    ("s1", 24, 16, 256, 0, {"tile_size": (4, 4)}),   # 1024 spp, depth 0 only: 32 pixels see the fractal (Color) AND an emissive proxy (Background, a later object) -> the
+                                                      # Background samples are NOT a prefix of the add order: k_resolve_blk's flag-per-term fallback
     ("s1", 8, 8, 256, 12, {"tile_size": (4, 4)}),    # config 4's regime: 1024 spp, 12 bounces
     ("s2", 16, 8, 256, 8, {"tile_size": (4, 4)}),    # config 3's regime: 1024 spp (resolve sorts 1024 keys), 8 bounces, volume; 4x4 tiles keep the oracle fast
 ]
