@@ -300,11 +300,11 @@ def main():
         npool = st["paths"]
         qk = {
             "k_raygen": (st["ms_raygen"], 85.0 * npool),                      # 5 records of 16 B + term_info + queue entry per path
-            "bin(k_group_hist+k_scan_tile+k_tile_prefix+memset+k_bin_scatter)": (st["ms_bin"], st["queue_bytes_bin"]),
-            "compact(k_scan_tile+k_tile_prefix+memset+k_compact_scatter)": (st["ms_compact"], st["queue_bytes_compact"]),
+            "bin(k_group_hist+k_scan_tile+k_tile_prefix+k_bin_scatter)": (st["ms_bin"], st["queue_bytes_bin"]),
+            "compact(k_scan_tile+k_tile_prefix+k_compact_scatter)": (st["ms_compact"], st["queue_bytes_compact"]),
             "k_resolve": (st["ms_resolve"], 37.0 * npool + 40.0 * W * H / world),  # col0 + aov + termination record per path, film out
         }
-        qk["k_shadow1 (queue side: 4 B ref + 32 B segment in, 1 B visibility out per shadow job; the kernel itself is VALU-bound)"] = (st["ms_shadow"], 37.0 * st["shadow_jobs"])
+        qk["k_shadow1 (queue side: 4 B ref + 24 B segment in, 1 B visibility out per shadow job; the kernel itself is VALU-bound)"] = (st["ms_shadow"], 29.0 * st["shadow_jobs"])
         roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shadow_jobs": st["shadow_jobs"], "kernels": {}}
         for name, (ms_k, nbytes) in qk.items():
             ach = nbytes / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
