@@ -1,6 +1,6 @@
 # round 4, first GPU pass: parity suite (new shipped / bulb / per-rank tests), the shipped workload's bench line, where a cold start goes, baseline shares
 set -x
-cd $GRAFT_REPO_ROOT
+cd $GRAFT_REPO_ROOT  # (these scripts are run as: gpurun -- bash tools/passes_r04/<name>.sh)
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 timeout 300 python bench.py --workload shipped 2>&1 | tail -1 > gpurun_out/r04_bench_shipped_a.json; cut -c1-600 gpurun_out/r04_bench_shipped_a.json
