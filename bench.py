@@ -12,6 +12,9 @@ frame is partitioned by tiles (rotating round-robin) across ranks and gathered t
 
   python bench.py --gpus 1 --steps 2 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N ...                    (WORLD_SIZE unset: relaunches itself under torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --single-process ...   (ONE process, one rayn_hip_create_multi context over N GPUs, peer-copy gather:
+                                                   what a rayn host bound per bindings/ runs for src/film.rs:630-658)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. "roofline" (dominant kernel
 class, HIP-event timed live) and "cpu_baseline" (the CPU oracle on a bounded tile sample, N=1 only).
@@ -64,7 +67,16 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-FLOP_PER_DIST = 404.0  # MandelBox::dist, 12 iterations x 33 + 8, fma = 2
+# Flop of ONE evaluation of a scene's SDF = per_iteration x (fold / orbit iterations the evaluation ran) + per_evaluation, mul = add = div = sqrt = 1
+# (the reference's default build has no fma).  Iterations are COUNTED by the instrumented kernels (rayn_hip_get_sdf_iterations), not assumed.
+#   MandelBox::dist (src/sdf.rs:125-188): per fold iteration 3 clamps (min + max: 6) + 3 mul_add (6) for the box fold, 5 for r^2, max + div + max (3) and 4
+#     multiplies of the sphere fold, 4 mul_add (8) + a negation for scale + offset = 33; epilogue |p| (6) + abs + div = 8  ->  12 x 33 + 8 = 404
+#   Mandelbulb (EXTENSION, device_core.h::mandelbulb_dist, polynomial power-8 form): per orbit step m^2, m^4 (2), dz (6), the six squares / fourth powers (6),
+#     k3 (1), k2 = 1 / sqrt(k3^7) (8), k1 (11), k4 (2), w.x (15), w.y (7), w.z (20), |w|^2 (5), bailout compare (1) = 84; prologue |p|^2 (5) +
+#     epilogue 0.25 ln(m) sqrt(m) / dz (5, the logarithm counted as ONE) = 10  ->  at most 8 x 84 + 10 = 682, less when the orbit escapes early
+#   sdfu::Sphere: |p| - r = 7, no iterations
+SDF_FLOPS = {"mandelbox": (33.0, 8.0), "mandelbulb": (84.0, 10.0), "sphere": (0.0, 7.0)}
+SCENE_SDF = {"s0": "sphere", "s1": "mandelbox", "s2": "mandelbox", "s3": "mandelbox", "ship": "mandelbox", "bulb": "mandelbulb", "bulbv": "mandelbulb"}
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= f32-input MFMA peak)
 HBM_PEAK_GBS = 8000.0
 
@@ -77,6 +89,10 @@ WORKLOADS = {
     "c5": ("s3", 7680, 4320, 1024, 16, "7680x4320, 4096 spp, 16 bounces, MandelBox SDF, moving camera with time-sampled motion blur "
            "[BASELINE configs[4], an 8-GPU config: 135.9 G paths; the reference's SDF itself is not time-dependent]"),
     "bulb": ("bulb", 1920, 1080, 64, 8, "1920x1080, 256 spp, 8 bounces, power-8 Mandelbulb SDF (EXTENSION: the fractal BASELINE.json names; not in the reference), volumes off"),
+    # the metric's LITERALLY named workload: configs[2]'s size with the fractal BASELINE.json names.  The reference has no Mandelbulb (its only fractal is
+    # the MandelBox of src/sdf.rs:104-141), so nothing in rayn corresponds to this line: it measures the HIP path on the restated extension
+    "bulb3": ("bulbv", 1920, 1080, 256, 8, "1920x1080, 1024 spp, 8 bounces, power-8 Mandelbulb SDF + homogeneous volume (rho_s 0.25, rho_t 0.035) [BASELINE metric as literally named; "
+              "the Mandelbulb is an EXTENSION - the reference's only fractal is a MandelBox, src/sdf.rs:104-141, so no rayn number can correspond]"),
     # the reference's OWN workload, the only thing rayn itself times (src/main.rs:47-82 on src/setup.rs:46-170 as shipped): here the first
     # frame of a fresh context (cold_ms) is the number that corresponds to a rayn run, and the CPU leg renders the WHOLE frame in the GPU's own 16x16 tiles
     "shipped": ("ship", 1280, 720, 2, 3, "1280x720, 8 spp (SAMPLES = 2), 3 bounces, MandelBox SDF + homogeneous volume, frame 1: the reference's shipped default "
@@ -102,9 +118,23 @@ def main():
     ap.add_argument("--check-film", action="store_true", help="rank 0 re-renders the whole frame alone after the timed region and compares it bit for bit with the gathered film")
     ap.add_argument("--gather-only", action="store_true", help="diagnosis of the N>1 exchange: render the frame once, then time 20 film gathers alone "
                     "(barrier before each) and print per-rank / per-iteration gather times instead of the bench line - separates the xGMI gather from render skew")
+    ap.add_argument("--single-process", action="store_true", help="N GPUs inside ONE process: one rayn_hip_create_multi context over devices 0..N-1 (peer-copy film gather over "
+                    "xGMI, no process group) - the path a rayn host bound per bindings/ uses for src/film.rs:630-658; same JSON line with per-device render times")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barrier, all-reduce, FilmGather incl. rank 0's own block) even at "
                     "world size 1: executes the RCCL path of the multi-GPU launch on a one-GPU box")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
+        # `python bench.py --gpus N` without a launcher: become the driver's own launch line (one rank per GPU under torch.distributed.run).
+        # exec, not spawn: same stdout (ONE JSON line from rank 0), same exit code, nothing of this process left behind.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: relaunching as `%s`\n" % (args.gpus, " ".join(cmd[1:10]) + " ..."))
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
     quick = args.workload in ("shipped", "c1", "small")
     if args.steps is None:
         args.steps = 20 if quick else 2
@@ -122,12 +152,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    n_devices = 1  # GPUs driven by THIS process (> 1 only with --single-process)
+    if args.single_process:
+        if world != 1:
+            sys.exit("bench.py: --single-process is one process over N GPUs; do not launch it under torch.distributed.run")
+        n_devices = args.gpus
+    elif world != args.gpus:
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    if args.single_process and not args.share_gpu and torch.cuda.device_count() < n_devices:
+        sys.exit(f"bench.py: --single-process --gpus {n_devices} needs {n_devices} visible GPUs ({torch.cuda.device_count()} here; --share-gpu puts all entries on GPU 0)")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -143,7 +178,7 @@ def main():
 
     scene, W, H, samples, bounces, desc = WORKLOADS[args.workload]
     spp = 4 * samples
-    cam, wld = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
+    cam, wld = S.SCENES[scene]((W, H))
     wd = wld.to_desc(cam)
     p = rayn_amd.frame_params(W, H, samples, bounces, tile_first=rank, tile_step=world)
     tabs = rayn_amd.build_tables(spp, bounces, p.volume_marches, p.frame, W, H)
@@ -151,12 +186,13 @@ def main():
     # context creation -> world upload -> first frame through the HOST-buffer entry (tables up, film down) on a context with no
     # device memory yet.  Outside the timed region; the same context then serves the warm-up and the timed steps.
     t_cold = time.perf_counter()
-    ctx = rayn_amd.Context(local_rank)
+    devices = ([0] * n_devices if args.share_gpu else list(range(n_devices))) if args.single_process else None
+    ctx = rayn_amd.Context(devices if devices is not None else local_rank)
     ctx.upload_world(wd)
     ctx.set_fma_policy(args.fma_policy)
     cold_ms = None
     cold_detail = None
-    if not use_dist and not args.no_cold:
+    if not use_dist and not args.no_cold and n_devices == 1:
         t_created = time.perf_counter()
         ctx.render_host(p, tabs)
         cold_ms = (time.perf_counter() - t_cold) * 1e3
@@ -166,23 +202,33 @@ def main():
                                "code objects loaded, film down).  A torch-less host (tools/cold_frame.py) pays 200-244 ms from process start for the shipped workload"}
     d_tabs = [torch.from_numpy(t).to(device) for t in tabs]  # resident in HBM before the timed region
     film = rayn_amd.film.alloc_device_film(W, H, device)
-    gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo"), force=args.force_dist) if use_dist else None
+    # ranks other than 0 resolve their share straight into the gather's packed send block (no full-resolution film, no pack step)
+    gather = FilmGather(W, H, (p.tile_w, p.tile_h), rank, world, device, stage_host=(args.backend == "gloo"), force=args.force_dist, ctx=ctx, params=p) if use_dist else None
 
     # per-rank diagnosis of an N>1 run (all-gathered after the timed region): HIP-event time of the render (rayn_stats.ms_total, events
     # on the caller's stream around the whole share), host wall time of the render call, and the gather (pack + collective + scatter,
     # fenced with a device synchronise - the render call is blocking already, and the next frame follows the gather on the same stream,
     # so the fence costs one host round trip)
     acc = {"render_ms": 0.0, "render_wall_ms": 0.0, "gather_ms": 0.0}
+    dev_acc = [{"render_ms": 0.0, "segments": 0, "batches": 0, "tiles": 0} for _ in range(n_devices)]  # --single-process: per entry of the context
 
     def step(timed=False):
         t_a = time.perf_counter()
-        ctx.render_device(p, d_tabs, film)
+        if gather is not None:
+            gather.render(d_tabs, film)
+        else:
+            ctx.render_device(p, d_tabs, film)
         t_b = time.perf_counter()
         res = film
         if gather is not None:
             res = gather.gather(film)
             torch.cuda.synchronize()
         t_c = time.perf_counter()
+        if timed and n_devices > 1:
+            for e, d in enumerate(dev_acc):
+                es = ctx.entry_stats(e)
+                d["render_ms"] += es["ms_total"]
+                d["segments"], d["batches"], d["tiles"] = es["segments"], es["batches"], es["tiles"]
         if timed:
             acc["render_ms"] += ctx.stats()["ms_total"]
             acc["render_wall_ms"] += (t_b - t_a) * 1e3
@@ -222,7 +268,8 @@ def main():
             mine.append((time.perf_counter() - t_a) * 1e3)
         allr = all_gather_vec(mine)
         if rank == 0:
-            print(json.dumps({"mode": "gather-only", "metric": "film gather (pack + one dist.gather + scatter on rank 0), ms", "n_gpus": world, "iterations": iters,
+            print(json.dumps({"mode": "gather-only", "metric": "film gather (ONE dist.gather of the ranks' packed planar blocks + one k_unpack_tiles launch per block on rank 0; "
+                              "no pack step: ranks resolve into their send block), ms", "n_gpus": world, "iterations": iters,
                               "backend": args.backend, "bytes_per_rank": gather.block * 40, "pixels_per_rank": gather.counts,
                               "rank0_ms": [round(v, 3) for v in allr[0]], "per_rank_mean_ms": [round(sum(r) / len(r), 3) for r in allr],
                               "per_rank_min_ms": [round(min(r), 3) for r in allr], "workload": desc}), flush=True)
@@ -251,10 +298,17 @@ def main():
                     "gather_ms": [round(r[2], 3) for r in rows], "segments": [int(r[3]) for r in rows], "batches": [int(r[4]) for r in rows],
                     "tiles": [int(r[5]) for r in rows]}
     film_check = None
-    if use_dist and args.check_film and rank == 0:  # outside the timed region: the whole frame on this rank alone
+    if (use_dist or n_devices > 1) and args.check_film and rank == 0:  # outside the timed region: the whole frame on ONE device of this rank alone
         p_full = rayn_amd.frame_params(W, H, samples, bounces)
         film_full = rayn_amd.film.alloc_device_film(W, H, device)
-        ctx.render_device(p_full, d_tabs, film_full)
+        if n_devices > 1:
+            solo = rayn_amd.Context(local_rank)
+            solo.upload_world(wd)
+            solo.set_fma_policy(args.fma_policy)
+            solo.render_device(p_full, d_tabs, film_full)
+            solo.close()
+        else:
+            ctx.render_device(p_full, d_tabs, film_full)
         torch.cuda.synchronize()
         film_check = all(torch.equal(result[k].view(torch.int32), film_full[k].view(torch.int32)) for k in ("color", "alpha", "background", "normal"))
         del film_full
@@ -263,7 +317,8 @@ def main():
 
     roofline = None
     roofline_hbm = None
-    if not args.no_roofline:
+    kernel_ms = None
+    if not args.no_roofline and n_devices == 1:
         # (1) per-kernel-class HIP-event timing with the production kernels, (2) SDF-evaluation counts with
         # the instrumented variants.  Both outside the timed region.
         # per-kernel event times are only meaningful without the two-worker overlap: profile with ONE worker
@@ -276,25 +331,41 @@ def main():
         ctx.render_device(p, d_tabs, film)
         torch.cuda.synchronize()
         ev = ctx.eval_counts()
+        it = ctx.sdf_iterations()
         ctx.set_profiling(False, False)
         ctx.set_workers(2)
-        classes = {"extend": (st["ms_extend"], ev["extend"], st["launches_extend"]), "shadow": (st["ms_shadow"], ev["shadow"], st["launches_shade"]),
-                   "shade_setup": (st["ms_shade"], ev["shade_setup"], st["launches_shade"])}
+        # flop of the evaluations = per-iteration flop x the iterations the instrumented kernels COUNTED + the per-evaluation part (SDF_FLOPS):
+        # exactly 404 per evaluation for the shipped MandelBox; the Mandelbulb's orbits escape early, so its average is below the 682 of 8 full steps
+        sdf_kind = SCENE_SDF[scene]
+        f_it, f_ev = SDF_FLOPS[sdf_kind]
+        flops = {k: f_it * it[k] + f_ev * ev[k] for k in ev}
+        classes = {"extend": (st["ms_extend"], ev["extend"], st["launches_extend"], flops["extend"]), "shadow": (st["ms_shadow"], ev["shadow"], st["launches_shade"], flops["shadow"]),
+                   "shade_setup": (st["ms_shade"], ev["shade_setup"], st["launches_shade"], flops["shade_setup"])}
         dom = max(classes, key=lambda k: classes[k][0])
-        ms, evals, launches = classes[dom]
-        achieved = FLOP_PER_DIST * evals / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # "bound" uses the contract's vocabulary (hbm | mfma = the compute roof); the compute roof of this path is the FP32
-        # VECTOR pipe - nothing here is a dense contraction, no MFMA instruction is issued (see bound_detail)
+        ms, evals, launches, flop = classes[dom]
+        achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        flop_per_eval = flop / evals if evals else 0.0
+        all_flop = sum(v[3] for v in classes.values())
+        frame_tflops = all_flop / (st["ms_total"] * 1e-3) / 1e12 if st["ms_total"] > 0 else 0.0
+        # "bound" names what the kernel is bound by: the FP32 VECTOR pipe (VALU) - nothing here is a dense contraction and no MFMA instruction is
+        # issued; "bound_contract" keeps the bench contract's two-word vocabulary (hbm | mfma = "the compute roof")
         kname = {"extend": "k_extend1", "shadow": "k_shadow1", "shade_setup": "k_shade_setup"}[dom]
-        roofline = {"kernel": f"{kname} [FP32 VALU-bound; no MFMA instruction is issued anywhere on this path]", "bound": "mfma", "bound_detail": "compute-bound on the FP32 VALU (divergent scalar math, no MFMA issued); "
+        roofline = {"kernel": f"{kname} [FP32 VALU-bound; no MFMA instruction is issued anywhere on this path]", "bound": "valu", "bound_contract": "mfma",
+                    "bound_detail": "compute-bound on the FP32 VALU (divergent scalar math, no MFMA issued); "
                     "peak = MI355X dense FP32 peak, 157.3 TFLOP/s for the vector pipe and for f32-input MFMA alike",
                     "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
                     "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                    "flop_per_launch": FLOP_PER_DIST * evals / max(launches, 1), "dist_evals": evals,
-                    "all_march_kernels": {k: {"ms": round(v[0], 3), "dist_evals": v[1],
-                                              "tflops": round(FLOP_PER_DIST * v[1] / max(v[0], 1e-9) / 1e9, 3)} for k, v in classes.items()},
-                    "note": "march kernels are FP32-VALU bound (SURVEY.md F6): achieved = 404 flop x SDF evals / kernel time; "
+                    "flop_per_launch": flop / max(launches, 1), "dist_evals": evals,
+                    "sdf": sdf_kind, "flop_per_dist_eval": round(flop_per_eval, 2), "sdf_iterations": it[dom],
+                    "flop_model": f"{f_it:g} flop per fold / orbit iteration x counted iterations + {f_ev:g} per evaluation (bench.py SDF_FLOPS; iterations and evaluations counted "
+                                  "by the instrumented kernel variants outside the timed region)",
+                    "whole_frame": {"tflops": round(frame_tflops, 3), "frac": round(frame_tflops / FP32_VECTOR_PEAK_TFLOPS, 4),
+                                    "note": "SDF-evaluation flop of ALL three march classes over the whole frame's HIP-event time (queue kernels, shading arithmetic and the film resolve "
+                                            "count as time but not as flop)"},
+                    "all_march_kernels": {k: {"ms": round(v[0], 3), "dist_evals": v[1], "flop_per_dist_eval": round(v[3] / v[1], 2) if v[1] else 0.0,
+                                              "tflops": round(v[3] / max(v[0], 1e-9) / 1e9, 3)} for k, v in classes.items()},
+                    "note": "march kernels are FP32-VALU bound (SURVEY.md F6): achieved = SDF-evaluation flop / kernel time; "
                             "peak = MI355X FP32 vector peak (= dense f32-input MFMA peak)"}
         # HBM-bound queue kernels: algorithmic bytes / HIP-event time per kernel class
         npool = st["paths"]
@@ -311,7 +382,7 @@ def main():
             roofline_hbm["kernels"][name] = {"ms": round(ms_k, 3), "algorithmic_bytes": nbytes, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
         # PMC traffic is measured by separate rocprofv3 --pmc passes (tools/gpu_round.sh) and committed under profiles/ with the
         # hash of the kernel sources it was taken on; a file that does not match the sources of THIS build is not quoted.
-        pmc_name = next((n for n in (f"r04_pmc_hbm_{args.workload}.json", f"r03_pmc_hbm_{args.workload}.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        pmc_name = next((n for n in (f"r05_pmc_hbm_{args.workload}.json", f"r04_pmc_hbm_{args.workload}.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         pmc_path = os.path.join(ROOT, "profiles", pmc_name or "")
         if pmc_name and world == 1 and args.fma_policy == 0:
             pj = json.load(open(pmc_path))
@@ -324,6 +395,7 @@ def main():
                     # same file, same kernel sources: SQ counters of the dominant kernel.  A wave64 binary32 VALU instruction issues at
                     # one per 2 cycles per SIMD (what the 157.3 TFLOP/s peak is made of: 64 lanes x 2 flop / 2 cycles x 1024 SIMDs x 2.4 GHz)
                     ipc = pmc[kname]["valu_inst_per_cycle_simd"]
+                    roofline["lanes_enabled"] = round(pmc[kname]["lanes_enabled"], 4)  # SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU): the exec-masked fold block
                     roofline["valu_issue"] = {"inst_per_cycle_simd": round(ipc, 4), "peak": 0.5, "frac": round(ipc / 0.5, 4),
                                               "lanes_enabled": round(pmc[kname]["lanes_enabled"], 4),
                                               "source": f"profiles/{pmc_name} (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
@@ -337,11 +409,9 @@ def main():
             else:
                 roofline["traffic_note"] = f"profiles/{pmc_name} was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"
         kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_shadow", "ms_finish", "ms_compact", "ms_resolve", "ms_total")}
-    else:
-        kernel_ms = None
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and n_devices == 1 and args.cpu_seconds > 0:
         from oracle import oracle_py as O
         threads = usable_cpus()  # what the container may use (cgroup quota), not the host's thread count
         # The oracle runs a tile serially on one thread (like the reference).  A 16x16 tile of this workload is about a minute
@@ -384,11 +454,15 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mpath-samples/sec", "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world, "steps": args.steps,
+            "metric": "Mpath-samples/sec", "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world * n_devices, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "paths_per_step": paths_per_step, "tile": [p.tile_w, p.tile_h], "fma_policy": "unfused (reference default build)" if args.fma_policy == 0 else "fused (reference built with +fma)",
-                       "parallelism": f"tiles round-robin over {world} GPU(s)" + (", one RCCL gather of the owned pixels to rank 0 per frame" if use_dist else "")},
+                       "parallelism": f"tiles round-robin over {world * n_devices} GPU(s)" +
+                                      (", one RCCL gather of the ranks' packed planar blocks to rank 0 per frame (ranks resolve straight into their send block; rank 0 unpacks "
+                                       "with one kernel launch per block); every frame is fenced after its gather (per-rank gather_ms)" if use_dist else "") +
+                                      (f", ONE process: a rayn_hip_create_multi context over devices {devices} (one host thread + renderer per device, one hipMemcpyPeerAsync of its "
+                                       "packed block per peer over xGMI, one unpack launch per block on devices[0]); no process group" if n_devices > 1 else "")},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "kernel_ms": kernel_ms,
             "segments_per_step": segments_per_step,
             "cold_ms": None if cold_ms is None else round(cold_ms, 1),  # fresh context -> first frame done (host buffers), see above
@@ -406,6 +480,15 @@ def main():
             out["gather_ms"] = per_rank["gather_ms"][0]
             mean_r = sum(per_rank["render_ms"]) / len(per_rank["render_ms"])
             out["imbalance"] = round(max(per_rank["render_ms"]) / mean_r, 4) if mean_r > 0 else None
+        if n_devices > 1:
+            # per DEVICE of the one context: HIP-event time of its own share on its own stream, its segments / batches / tiles; exchange_ms = the
+            # frame on devices[0]'s clock minus the slowest device's render = table broadcast + peer copies + unpack (what the gather costs)
+            rms = [d["render_ms"] / args.steps for d in dev_acc]
+            out["per_device"] = {"render_ms": [round(v, 3) for v in rms], "segments": [d["segments"] for d in dev_acc], "batches": [d["batches"] for d in dev_acc],
+                                 "tiles": [d["tiles"] for d in dev_acc]}
+            out["exchange_ms"] = round(acc["render_ms"] / args.steps - max(rms), 3)
+            mean_r = sum(rms) / len(rms)
+            out["imbalance"] = round(max(rms) / mean_r, 4) if mean_r > 0 else None
         if film_check is not None:
             out["film_check"] = film_check  # gathered film == single-rank film, bit for bit
         if use_dist and args.backend != "nccl":

@@ -234,6 +234,28 @@ int rayn_hip_render_frame_device(rayn_ctx* ctx, const rayn_frame_params* p,
                                  float* d_out_normal, void* hip_stream);
 
 int rayn_hip_get_stats(const rayn_ctx* ctx, rayn_stats* out);
+/* entry 0 .. rayn_hip_device_count() - 1 of a multi-device context: what THAT device did in the last frame (its own tiles, segments,
+ * batches; ms_total = HIP events around its share on its own stream, table broadcast and film copy excluded) - rayn_hip_get_stats holds
+ * the sums and, in ms_total, the whole multi-device frame on devices[0]'s clock.  A single-device ctx has the one entry 0. */
+int rayn_hip_get_entry_stats(const rayn_ctx* ctx, int entry, rayn_stats* out);
+
+/* ---- the film gather of a multi-PROCESS launch (one process per GPU; no reference counterpart: tiles are independent,
+ * src/film.rs:439-627, and the reference's tile_finished copies each finished tile into the one film, src/film.rs:660-691) ----
+ * A rank that owns the share (tile_first, tile_step) renders it straight into a PACKED PLANAR film of its own pixels - no
+ * full-resolution film exists on that rank and nothing is packed afterwards: Color 3N | Alpha N | Background 3N | WorldNormal 3N
+ * floats for the N = rayn_share_pixels(p) pixels of its tiles, tile after tile in ascending reference tile order, pixel-major (x outer,
+ * y inner) inside a tile.  That buffer is what crosses xGMI (ONE ncclGather / peer copy); the receiving rank scatters it into its
+ * full-resolution film with rayn_hip_unpack_share_device (p carrying the SENDER's tile_first / tile_step): one kernel launch,
+ * enqueued on hip_stream and not waited for; the share's tile list is uploaded the first time a share is seen and cached in the ctx.
+ * It is the same packed layout and the same two kernels rayn_hip_create_multi uses between the devices of one process. */
+uint64_t rayn_share_pixels(const rayn_frame_params* p);
+int rayn_hip_render_frame_packed_device(rayn_ctx* ctx, const rayn_frame_params* p,
+                                        const float* d_samples_1d, const float* d_samples_2d,
+                                        const float* d_scramble, const float* d_fis_table,
+                                        float* d_packed /* 10 * rayn_share_pixels(p) floats */, void* hip_stream);
+int rayn_hip_unpack_share_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_packed,
+                                 float* d_out_color, float* d_out_alpha, float* d_out_background,
+                                 float* d_out_normal, void* hip_stream);
 
 /* ---- host-side table builders (the a1/a3/a4 rows of SURVEY.md section 8) ------------------ */
 /* 1 + requested_1d_sample_sets(), 2 + requested_2d_sample_sets() (src/film.rs:431-432,
@@ -264,6 +286,10 @@ uint32_t rayn_tile_count(uint32_t width, uint32_t height, uint32_t tile_w, uint3
 int rayn_hip_set_profiling(rayn_ctx* ctx, int timing, int count_evals);
 /* out[0] k_extend (closest-hit marches), out[1] k_shade_setup (normal estimation), out[2] k_shadow (NEE visibility) */
 int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
+/* the fold / orbit ITERATIONS those evaluations ran, same three kernels (MandelBox::dist always runs `iterations` folds, src/sdf.rs:125-141;
+ * the Mandelbulb extension stops at its bailout; a sphere SDF has none): what an evaluation of the scene's own SDF costs is
+ * flop_per_iteration * iterations / evaluations + the epilogue - bench.py prices the roofline with it instead of a fixed figure */
+int rayn_hip_get_sdf_iterations(const rayn_ctx* ctx, uint64_t out[3]);
 /* A frame's tiles are dealt to up to two workers (host thread + HIP stream + own device memory each) so that one
  * worker's HBM-bound kernels and readbacks run underneath the other's VALU-bound marches.  n_workers 1..4 (default 2).
  * A further worker is only used while every worker still gets full-size batches and the call owns >= min_paths camera

@@ -35,6 +35,7 @@ EXPORTS = [
     "rayn_build_scramble", "rayn_build_fis_table", "rayn_build_fis_table_ex", "rayn_tile_count", "rayn_hip_set_profiling", "rayn_hip_get_eval_counts",
     "rayn_hip_set_batch_paths", "rayn_hip_set_cold_bytes", "rayn_hip_set_workers", "rayn_hip_set_tile_subset", "rayn_hip_set_trace_tile", "rayn_hip_get_trace", "rayn_hip_fma_policy", "rayn_hip_set_fma_policy", "rayn_hip_sizeof", "rayn_hip_probe_sdf_dist",
     "rayn_hip_probe_closest_hit", "rayn_hip_probe_occluded", "rayn_hip_probe_detmath", "rayn_hip_build_variant",
+    "rayn_hip_get_entry_stats", "rayn_hip_get_sdf_iterations", "rayn_share_pixels", "rayn_hip_render_frame_packed_device", "rayn_hip_unpack_share_device",
 ]
 
 
@@ -75,6 +76,11 @@ def lib():
         L.rayn_hip_render_frame.argtypes = [vp, C.POINTER(_abi.FrameParams), fp, fp, fp, fp, fp, fp, fp, fp]
         L.rayn_hip_render_frame_device.argtypes = [vp, C.POINTER(_abi.FrameParams)] + [vp] * 9
         L.rayn_hip_get_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
+        L.rayn_hip_get_entry_stats.argtypes = [vp, C.c_int, C.POINTER(_abi.Stats)]
+        L.rayn_share_pixels.restype = C.c_uint64
+        L.rayn_share_pixels.argtypes = [C.POINTER(_abi.FrameParams)]
+        L.rayn_hip_render_frame_packed_device.argtypes = [vp, C.POINTER(_abi.FrameParams)] + [vp] * 6
+        L.rayn_hip_unpack_share_device.argtypes = [vp, C.POINTER(_abi.FrameParams)] + [vp] * 6
         L.rayn_sets_1d.restype = C.c_uint32
         L.rayn_sets_1d.argtypes = [C.c_uint32, C.c_uint32]
         L.rayn_sets_2d.restype = C.c_uint32
@@ -87,6 +93,7 @@ def lib():
         L.rayn_tile_count.argtypes = [C.c_uint32] * 4
         L.rayn_hip_set_profiling.argtypes = [vp, C.c_int, C.c_int]
         L.rayn_hip_get_eval_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.rayn_hip_get_sdf_iterations.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rayn_hip_set_batch_paths.argtypes = [vp, C.c_uint64]
         L.rayn_hip_set_cold_bytes.argtypes = [vp, C.c_uint64]
         L.rayn_hip_set_workers.argtypes = [vp, C.c_int, C.c_uint64]

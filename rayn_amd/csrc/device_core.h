@@ -165,13 +165,19 @@ RD float fis_sample(const float* __restrict__ inverse_cdf, float u) {
     return mult * lerpf(inverse_cdf[idx], inverse_cdf[idx + 1], t);
 }
 
+// Counters of the instrumented (COUNT = true) kernel variants - roofline accounting outside the timed region: SDF distance evaluations and
+// the fold / orbit ITERATIONS they ran (MandelBox: always `iterations`; Mandelbulb: until bailout), from which bench.py prices an evaluation
+// of the scene's own SDF.  Dead code in the product kernels (COUNT = false).
+struct EvalCtr { uint32_t n = 0, it = 0; };
+
 // ---- SDFs (src/sdf.rs:104-188; sdfu::Sphere) ---------------------------------------------------------
 // EXTENSION (not in the reference): power-8 Mandelbulb distance estimator, trigonometry-free polynomial form.
 // Plain IEEE f32 operations in exactly this order (the oracle restates them lane by lane).
 // The logarithm is kept OUT of line: inlined, its twelve binary64 coefficients are hoisted into 24 scalar registers for the
 // whole march kernel, which then sits at the 102-SGPR ceiling and marches MandelBox scenes 4 % slower (k_shadow1, c3).
 __device__ __attribute__((noinline)) static float bulb_logf(float m) { return dm_logf(m); }
-RD float mandelbulb_dist(f3 p, uint32_t iterations) {
+template <bool COUNT>
+RD float mandelbulb_dist(f3 p, uint32_t iterations, EvalCtr& evals) {
     f3 w = p;
     float m = w.x * w.x + w.y * w.y + w.z * w.z;
     float dz = 1.0f;
@@ -189,7 +195,7 @@ RD float mandelbulb_dist(f3 p, uint32_t iterations) {
         w.y = p.y + -16.0f * y2 * k3 * k4 * k4 + k1 * k1;
         w.z = p.z + -8.0f * y * k4 * (x4 * x4 - 28.0f * x4 * x2 * z2 + 70.0f * x4 * z4 - 28.0f * x2 * z2 * z4 + z4 * z4) * k1 * k2;
         m = w.x * w.x + w.y * w.y + w.z * w.z;
-        if (m > 256.0f) break;
+        if (m > 256.0f) { if (COUNT) evals.it -= iterations - 1u - i; break; } // orbit steps NOT run (roofline accounting only)
     }
     return 0.25f * bulb_logf(m) * sqrt_rn(m) / dz;
 }
@@ -266,8 +272,8 @@ RD float sdf_scale(const DHitable& h, float t0) { return h.scale_vel != 0.0f ? h
 #define RAYN_BOX_FMA(c, q) __builtin_fmaf(c, 2.0f, -(q))
 #define RAYN_FOLD_X4(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX)
 template <bool COUNT>
-RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
-    if (COUNT) evals++;
+RD float sdf_dist(const DHitable& h, f3 p, EvalCtr& evals, float scale) {
+    if (COUNT) { evals.n++; evals.it += h.sdf_kind == RAYN_SDF_SPHERE ? 0u : h.iterations; } // the Mandelbulb takes its early exits off again (mandelbulb_dist)
     if (h.sdf_kind == RAYN_SDF_MANDELBOX) {
         const f3 offset = p;
         float dr = 1.0f;
@@ -296,7 +302,7 @@ RD float sdf_dist(const DHitable& h, f3 p, uint32_t& evals, float scale) {
         }
         return mag(p) / __builtin_fabsf(dr);
     }
-    if (h.sdf_kind == RAYN_SDF_MANDELBULB) return mandelbulb_dist(p, h.iterations);
+    if (h.sdf_kind == RAYN_SDF_MANDELBULB) return mandelbulb_dist<COUNT>(p, h.iterations, evals);
     return mag(p) - h.sdf_radius;
 }
 #undef RAYN_FOLD_X4
@@ -324,7 +330,7 @@ RD f3 sphere_center(const DHitable& h, float t0) { return h.animated ? h.center 
 
 // TracedSDF::hit, src/sdf.rs:59-83 (per lane; a stopped lane is idempotent in the packet loop)
 template <bool COUNT>
-RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, const Thr& th, float t0, uint32_t& evals) {
+RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, const Thr& th, float t0, EvalCtr& evals) {
     o = o - sphere_center(h, t0);
     const float sv = sdf_scale(h, t0);
     float t = sdf_dist<COUNT>(h, o, evals, sv);
@@ -342,7 +348,7 @@ RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, c
 }
 // TracedSDF::occluded, src/sdf.rs:25-57 (returns 1 = visible, 0 = occluded)
 template <bool COUNT>
-RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, float t0, uint32_t& evals) {
+RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, float t0, EvalCtr& evals) {
     const f3 origin = sphere_center(h, t0);
     start = start - origin;
     end = end - origin;
@@ -366,7 +372,7 @@ RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, flo
 }
 // sdfu normals_fast (tetrahedron), called at src/sdf.rs:94-96
 template <bool COUNT>
-RD f3 sdf_normal(const DHitable& h, f3 p, float eps, uint32_t& evals, float sv) {
+RD f3 sdf_normal(const DHitable& h, f3 p, float eps, EvalCtr& evals, float sv) {
     float d1 = sdf_dist<COUNT>(h, f3{p.x + eps, p.y + -eps, p.z + -eps}, evals, sv);
     float d2 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + -eps, p.z + eps}, evals, sv);
     float d3 = sdf_dist<COUNT>(h, f3{p.x + -eps, p.y + eps, p.z + -eps}, evals, sv);
@@ -426,7 +432,7 @@ RD float sphere_occluded(const DHitable& h, f3 start, f3 end, float t0) {
 
 // HitableStore::add_hits fold, src/hitable.rs:177-198: closest-so-far is the next t_max.
 template <bool COUNT>
-RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float t0, float* out_t, uint32_t* out_obj, uint32_t& evals) {
+RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float t0, float* out_t, uint32_t* out_obj, EvalCtr& evals) {
     float closest = sc.t_max;
     uint32_t id = OBJ_NONE;
     for (uint32_t k = 0; k < sc.n_hitables; k++) {
@@ -440,7 +446,7 @@ RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float t0, float
 // HitableStore::test_occluded, src/hitable.rs:164-168.  Every factor is exactly 0 or 1, so the
 // product is order-independent: analytic spheres first, SDF marches only if still visible.
 template <bool COUNT>
-RD float test_occluded(const DScene& sc, f3 start, f3 end, float t0, uint32_t& evals) {
+RD float test_occluded(const DScene& sc, f3 start, f3 end, float t0, EvalCtr& evals) {
     for (uint32_t k = 0; k < sc.n_hitables; k++)
         if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], start, end, t0) == 0.0f) return 0.0f;
     for (uint32_t k = 0; k < sc.n_hitables; k++)

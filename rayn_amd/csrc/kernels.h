@@ -8,6 +8,16 @@
 namespace rayn {
 
 constexpr uint32_t SCAN_NC_BIN = 16; // = RAYN_MAX_HITABLES: classes of the bin scan
+// k_resolve_blk's 32-bit sort key = depth:7 | offset of the termination slot inside the tile's binned segment of that depth.  The depth field needs 7 bits
+// (max_bounces <= 120), which leaves 25 for the offset; a tile's segment holds at most max_tile_pixels * spp slots + the x4 bin padding and the x64 tail.
+// resolve_keys_fit() is checked by the host for every frame share (run_worker): relaxing the host's tile / spp limits cannot silently spill the offset into the depth bits
+// (which would change the summation order) - it becomes an error instead.
+constexpr uint32_t RESOLVE_KEY_SHIFT = 25;
+static_assert(120u < (1u << (32 - RESOLVE_KEY_SHIFT)) - 1u, "depth field of the resolve key too narrow for max_bounces <= 120 (0x7F.. is NOKEY's prefix)");
+inline bool resolve_keys_fit(uint32_t max_tile_pixels, uint32_t spp) {
+    return (unsigned long long)max_tile_pixels * spp + SCAN_NC_BIN * 3ull + 64ull < (1ull << RESOLVE_KEY_SHIFT);
+}
+
 
 // Path pool (device pointers): one slot per camera path, records of 16 bytes so that a scattered
 // access costs one 128-bit gather per record instead of four 32-bit ones (the shade kernels were

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
     bool exhausted = false;
     // per-lane ray state
     bool has = false, first = false, nan = false;
-    uint32_t ent = 0, P = 0, k = 0, id = OBJ_NONE, m = 0, evals = 0, sbits = 0;
+    uint32_t ent = 0, P = 0, k = 0, id = OBJ_NONE, m = 0, sbits = 0;
+    EvalCtr evals;
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
     float closest = 0.0f, t = 0.0f, t0 = 0.0f;
     // fold over the hitables (src/hitable.rs:177-198) up to the next TracedSDF; finish the ray at the end
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
             }
         }
     }
-    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+    if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -243,7 +244,8 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     bool exhausted = false, endgame = false;
     // current ray
     bool c_has = false, first = false, nan = false;
-    uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0, evals = 0;
+    uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0;
+    EvalCtr evals;
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
     float c_pre = 0.0f, c_post = 0.0f, t = 0.0f;
     float c_scale = h.scale, n_scale = h.scale; // MandelBox scale at the packet time (extension; h.scale itself in the reference's case)
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
             }
         }
     }
-    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+    if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
 }
 
 constexpr uint32_t QUEUE_UNROLL = 8; // groups a wave of a queue-streaming kernel has in flight per trip (r4: 4 -> 8, bin -3 %, repack -3 %)
@@ -640,7 +642,7 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
     const uint32_t n_slots = ctl->b_groups << 6;
-    uint32_t evals = 0;
+    EvalCtr evals;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_slots) return; // whole waves: n_slots % 64 == 0
     const uint32_t P = bq[j];
@@ -868,7 +870,7 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
     }
     const uint64_t m = __ballot(is_alive); // the group's survivors: count for the repack scan, mask for the scatter's ranks
     if (lane == 0) { alive_mask[j >> 6] = m; bgrp_cnt[j >> 6] = (uint8_t)__popcll(m); }
-    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+    if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
 }
 
 // Dense list of the pending (sample, slot) pairs.  A block scans 256 * SCAN_ITEMS ids per trip; each wave takes whole 64-id groups
@@ -948,7 +950,8 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
     bool has = false, first = false, nan = false;
-    uint32_t ref = 0, k = 0, m = 0, evals = 0;
+    uint32_t ref = 0, k = 0, m = 0;
+    EvalCtr evals;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, wa = f3{0, 0, 0}, wb = f3{0, 0, 0};
     float max_dist = 0.0f, t = 0.0f, jt0 = 0.0f;
     auto next_sdf = [&]() { // advance k to the next TracedSDF; none left -> the segment is visible
@@ -1014,7 +1017,7 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
             else if (res == 1) { k++; next_sdf(); }
         }
     }
-    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+    if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
 }
 
 // Fast path of k_shadow for scenes with exactly one TracedSDF: uniform SDF parameters, and a
@@ -1033,7 +1036,8 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     uint32_t cur = 0, end = 0;
     bool exhausted = false, endgame = false;
     bool c_has = false, first = false, nan = false, n_has = false;
-    uint32_t ref = 0, n_ref = 0, m = 0, evals = 0;
+    uint32_t ref = 0, n_ref = 0, m = 0;
+    EvalCtr evals;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
     float max_dist = 0.0f, n_max = 0.0f, t = 0.0f;
     float c_scale = h.scale, n_scale = h.scale; // MandelBox scale at the packet time (extension)
@@ -1099,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             if (res >= 0) { if (res == 1) nee.vis[ref] = 1; c_has = false; } // only VISIBLE results are written (see Nee::vis)
         }
     }
-    if (COUNT && evals) atomicAdd(evals_out, (unsigned long long)evals);
+    if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
 }
 
 __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__ scp, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl,
@@ -1443,7 +1447,7 @@ __global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ s
     const float n = (float)spp;
     // ---- Color / Background in (depth, slot) order.  r4: the sort runs on 32-bit keys WITHOUT a payload - depth:7 | slot relative to
     // where the tile's binned segment began at that depth (k_tile_prefix keeps those bases per depth; a tile's segment is < 2^23 slots for
-    // <= 1024 pixels x 4096 spp) - and every sample then finds its rank in the sorted key array by binary search (keys of a pixel are
+    // <= 1024 pixels x 4096 spp, the offset field has RESOLVE_KEY_SHIFT = 25 bits and the host refuses a frame that could exceed it: resolve_keys_fit, kernels.h) - and every sample then finds its rank in the sorted key array by binary search (keys of a pixel are
     // distinct: a slot holds one path).  Half the registers, one shuffle + v_cmp + v_cndmask per compare-exchange instead of two shuffles,
     // a 64-bit compare and two selects.
     constexpr uint32_t NOKEY = 0xFFFFFFFFu; // depth <= 120: no real key has the top bit set
@@ -1457,7 +1461,7 @@ __global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ s
             const uint32_t info = pool.term_info[P0 + i];
             if (info != TERM_NONE) {
                 const uint32_t d = info & 0x7Fu;
-                k = (d << 23) | (pool.term_key[P0 + i] - base_hist[d * hist_stride + blockIdx.y]);
+                k = (d << RESOLVE_KEY_SHIFT) | (pool.term_key[P0 + i] - base_hist[d * hist_stride + blockIdx.y]);
                 bgm |= (info >> 7) << r;
             }
         }
@@ -1758,14 +1762,15 @@ __global__ void __launch_bounds__(256) k_unpack_tiles(const DTile* __restrict__ 
 __global__ void k_probe_dist(const DScene* __restrict__ scp, uint32_t hit_index, const float* __restrict__ pts, float* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t ev = 0;
+    EvalCtr ev;
     out[i] = sdf_dist<false>(scp->h[hit_index], f3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, ev, scp->h[hit_index].scale);
 }
 __global__ void k_probe_closest(const DScene* __restrict__ scp, uint32_t depth, const float* __restrict__ org, const float* __restrict__ dir,
                                 float* __restrict__ out_t, uint32_t* __restrict__ out_obj, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t ev = 0, obj;
+    EvalCtr ev;
+    uint32_t obj;
     float t;
     closest_hit<false>(*scp, f3{org[3 * i], org[3 * i + 1], org[3 * i + 2]}, f3{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]},
                        make_thr(*scp, depth), 0.0f, &t, &obj, ev);
@@ -1775,7 +1780,7 @@ __global__ void k_probe_closest(const DScene* __restrict__ scp, uint32_t depth, 
 __global__ void k_probe_occluded(const DScene* __restrict__ scp, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t ev = 0;
+    EvalCtr ev;
     out[i] = test_occluded<false>(*scp, f3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, f3{b[3 * i], b[3 * i + 1], b[3 * i + 2]}, 0.0f, ev);
 }
 __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {

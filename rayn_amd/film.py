@@ -45,6 +45,11 @@ def build_tables(spp, max_bounces, volume_marches, frame, width, height, filter=
     return s1, s2, scr, fis
 
 
+def share_pixels(params):
+    """rayn_share_pixels: pixels of the tiles the share (params.tile_first, params.tile_step) owns; its packed film is 10 floats each."""
+    return int(lib().rayn_share_pixels(C.byref(params)))
+
+
 class Context:
     """One rayn_ctx (one GPU).  Fails loudly when the HIP library or a GPU is missing."""
 
@@ -113,9 +118,21 @@ class Context:
         self._chk(self._L.rayn_hip_get_stats(self.h, C.byref(s)))
         return s.as_dict()
 
+    def entry_stats(self, entry):
+        """What device `entry` of a multi-device context did in the last frame (rayn_hip_get_entry_stats)."""
+        s = _abi.Stats()
+        self._chk(self._L.rayn_hip_get_entry_stats(self.h, int(entry), C.byref(s)))
+        return s.as_dict()
+
     def eval_counts(self):
         out = (C.c_uint64 * 3)()
         self._chk(self._L.rayn_hip_get_eval_counts(self.h, out))
+        return {"extend": out[0], "shade_setup": out[1], "shadow": out[2]}
+
+    def sdf_iterations(self):
+        """Fold / orbit iterations run by the evaluations of eval_counts() (instrumented kernels, rayn_hip_get_sdf_iterations)."""
+        out = (C.c_uint64 * 3)()
+        self._chk(self._L.rayn_hip_get_sdf_iterations(self.h, out))
         return {"extend": out[0], "shade_setup": out[1], "shadow": out[2]}
 
     def render_host(self, params, tables, out=None):
@@ -138,6 +155,25 @@ class Context:
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         self._chk(self._L.rayn_hip_render_frame_device(self.h, C.byref(params), ptr(d_tables[0]), ptr(d_tables[1]), ptr(d_tables[2]),
                                                        ptr(d_tables[3]), ptr(d_out["color"]), ptr(d_out["alpha"]),
+                                                       ptr(d_out["background"]), ptr(d_out["normal"]), C.c_void_p(s)))
+
+    def render_packed(self, params, d_tables, d_packed, stream=None):
+        """rayn_hip_render_frame_packed_device: the share (params.tile_first / tile_step) straight into its PACKED planar film
+        `d_packed` (a float32 CUDA tensor of >= 10 * share_pixels(params) elements) - what a rank hands to the film gather."""
+        import torch
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        assert d_packed.dtype == torch.float32 and d_packed.is_contiguous() and d_packed.numel() >= 10 * share_pixels(params)
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self._chk(self._L.rayn_hip_render_frame_packed_device(self.h, C.byref(params), ptr(d_tables[0]), ptr(d_tables[1]), ptr(d_tables[2]),
+                                                              ptr(d_tables[3]), ptr(d_packed), C.c_void_p(s)))
+
+    def unpack_share(self, params, d_packed, d_out, stream=None):
+        """rayn_hip_unpack_share_device: scatter the packed film of the share (params.tile_first / tile_step) into the full-resolution
+        film `d_out` with one kernel launch on the stream (enqueued, not waited for)."""
+        import torch
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self._chk(self._L.rayn_hip_unpack_share_device(self.h, C.byref(params), ptr(d_packed), ptr(d_out["color"]), ptr(d_out["alpha"]),
                                                        ptr(d_out["background"]), ptr(d_out["normal"]), C.c_void_p(s)))
 
     def close(self):

@@ -81,6 +81,12 @@ def setup_bulb(resolution=(1920, 1080), volumes=False):
     return setup(resolution, volumes=volumes, sdf="mandelbulb")
 
 
+def setup_bulb3(resolution=(1920, 1080)):
+    """EXTENSION scene of the metric's literally named workload ("1920x1080 Mandelbulb @1024spp" on configs[2]): the Mandelbulb
+    scene WITH the shipped homogeneous volume (rho_s 0.25, rho_t 0.035, src/setup.rs:58-59)."""
+    return setup(resolution, volumes=True, sdf="mandelbulb")
+
+
 def setup_s2(resolution=(1920, 1080)):
     """BASELINE config 3: shipped MandelBox scene with the homogeneous volume."""
     return setup(resolution, volumes=True, sdf="mandelbox")
@@ -100,3 +106,7 @@ def setup_s3(resolution=(7680, 4320), moving_fractal=True):
             if isinstance(h, TracedSDF):
                 h.transform_seq = Linear(vec3(0.0, 0.0, 0.0), vec3(-0.6, 0.45, 0.3))
     return camera, world
+
+
+# scene tag -> constructor (bench.py WORKLOADS, tests/golden/make_config_digests.py CONFIGS, tools/): "ship" = setup::setup() as shipped
+SCENES = {"s0": setup_s0, "s1": setup_s1, "s2": setup_s2, "s3": setup_s3, "bulb": setup_bulb, "bulbv": setup_bulb3, "ship": setup}

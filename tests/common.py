@@ -7,7 +7,7 @@ from rayn_amd import setup as S
 
 def case(name, width, height, samples, bounces, **kw):
     """Returns (world_desc, frame_params).  name: s0 (sphere SDF), s1 (MandelBox), s2 (MandelBox + volume), s3 (MandelBox, moving camera), ship (setup::setup() as shipped = s2)."""
-    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[name]((width, height))
+    cam, world = S.SCENES[name]((width, height))
     return world.to_desc(cam), P.frame_params(width, height, samples, bounces, **kw)
 
 

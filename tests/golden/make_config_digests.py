@@ -21,7 +21,7 @@ first tile, and evenly spaced quantiles of the ranking of the tiles that see mor
 
     python tests/golden/make_config_digests.py [c1 c2 c3 c4 c5 c1_fma c3_fma] [--tiles 12] [--jobs N]      (writes config_digests.json)
 
-About 15 core-minutes for c3, 5 for c4, 40 for c5, seconds for c1 (one tile runs serially on one thread, like the reference).
+About 15 core-minutes for c3 and bulb3, 5 for c4, 40 for c5, seconds for c1 (one tile runs serially on one thread, like the reference).
 Every entry is stamped with `oracle_hash` = sha256 of the sources that define the oracle's arithmetic (oracle/rayn_oracle.cpp,
 include/rayn_detmath.h, include/rayn_hip.h): tests/test_config_digests.py warns when the stamp no longer matches the tree and
 re-derives a cheap part of every entry on the CPU, so a fixture that predates an oracle change cannot go unnoticed.
@@ -50,6 +50,10 @@ CONFIGS = {
     "c5": ("s3", 7680, 4320, 1024, 16),
     # the fractal BASELINE.json names (extension scene, rayn_amd/setup.py::setup_bulb) at configs[1]'s size
     "bulb": ("bulb", 1920, 1080, 64, 8),
+    # the metric's literally named workload (BASELINE.json "1920x1080 Mandelbulb @1024spp" = configs[2] with the Mandelbulb extension):
+    # 1024 spp, 8 bounces, Mandelbulb + homogeneous volume (rho_s 0.25, rho_t 0.035).  The reference has no Mandelbulb (src/sdf.rs:104-141 is
+    # its only fractal), so nothing in rayn corresponds to these digests: they pin the HIP path to the oracle's restated extension.
+    "bulb3": ("bulbv", 1920, 1080, 256, 8),
     # the reference's OWN workload: src/main.rs:47-82 (1280x720, SAMPLES = 2 -> 8 spp, 3 bounces, frame 1, 16x16 tiles) on
     # src/setup.rs:46-170 as shipped (volumes on) - the WHOLE frame (3 600 tiles, 7.37 M paths)
     "shipped": ("ship", 1280, 720, 2, 3),
@@ -64,11 +68,29 @@ CHANNELS = ("color", "alpha", "background", "normal")
 
 def _code_only(text):
     """C/C++ source without comments and with whitespace collapsed: the stamp follows the ARITHMETIC, not the prose
-    (a citation added to a comment must not make every fixture look stale)."""
-    import re
-    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-    text = re.sub(r"//[^\n]*", " ", text)
-    return " ".join(text.split())
+    (a citation added to a comment must not make every fixture look stale).  A small scanner, not a regex: `//` or `/*` inside a
+    string or character literal is code, not a comment."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":  # string / character literal: copy verbatim up to the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+            out.append(" ")
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
 
 
 def oracle_hash():
@@ -93,7 +115,7 @@ def world_and_params(name, samples=None):
     from rayn_amd import setup as S
     scene, W, H, smp, bounces = CONFIGS[base_config(name)]
     # s3 = config 5: moving camera (reference-supported closure) + moving fractal (TracedSDF transform_seq extension)
-    cam, world = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
+    cam, world = S.SCENES[scene]((W, H))
     p = P.frame_params(W, H, smp if samples is None else samples, bounces)
     return world.to_desc(cam), p
 
@@ -182,9 +204,35 @@ def rederive_cheap_part(name, c, O, threads=None):
         assert tile_digests(film, p, t["tile"]) == t["sha256"], (name, t["tile"])
 
 
+def rederive_expensive_part(name, c, O, jobs=1):
+    """--restamp only: beyond the cheap part, re-derive with the oracle AS IT IS NOW the most expensive listed tile of every tile-sampled
+    entry (fractal-heavy: several segments per path; a minute or two of one core at 1024 spp) - for c5 (a 1.3 GB film per oracle call, ~4 minutes per
+    tile) the listed tile nearest the median cost - and two more tile columns of a column entry.  Returns what was verified (recorded in the entry)."""
+    fma = is_fma(name)
+    base = base_config(name)
+    if base == "c1":
+        return {"whole_frame": True}  # rederive_cheap_part already renders every tile of c1
+    wd, p = world_and_params(name)
+    tabs = O.build_tables(4 * p.samples, p.max_bounces, p.volume_marches, p.frame, p.width, p.height, fma=fma)
+    if base in COLUMN_CONFIGS:
+        ny = (p.height + p.height % p.tile_h) // p.tile_h
+        cols = [c["columns"][len(c["columns"]) // 2 + 2], c["columns"][len(c["columns"]) // 3]]
+        for col in cols:
+            tx = col["column"]
+            film, _ = O.render(wd, p, tabs, fma=fma, threads=jobs, tile_subset=list(range(tx * ny, tx * ny + ny)))
+            assert rect_digests(film, col["x"][0], 0, col["x"][1], p.height) == col["sha256"], (name, tx)
+        return {"columns": [col["column"] for col in cols]}
+    ranked = sorted(c["tiles"], key=lambda t: t["segments"])
+    t = ranked[len(ranked) // 2] if base == "c5" else ranked[-1]
+    film, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[t["tile"]], fma=fma)
+    assert (ctr.paths, ctr.segments, ctr.dist_evals) == (t["paths"], t["segments"], t["dist_evals"]), (name, t["tile"])
+    assert tile_digests(film, p, t["tile"]) == t["sha256"], (name, t["tile"])
+    return {"tiles": [t["tile"]], "segments": t["segments"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("configs", nargs="*", default=["c1", "c2", "c3", "c4", "c5", "bulb", "shipped", "c1_fma", "c3_fma", "shipped_fma"])
+    ap.add_argument("configs", nargs="*", default=["c1", "c2", "c3", "c4", "c5", "bulb", "bulb3", "shipped", "c1_fma", "c3_fma", "shipped_fma"])
     ap.add_argument("--tiles", type=int, default=12)
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--out", default=os.path.join(HERE, "config_digests.json"))
@@ -195,10 +243,17 @@ def main():
     O.build()
     result = json.load(open(args.out)) if os.path.exists(args.out) else {}
     if args.restamp:
-        for name, c in result.items():
-            rederive_cheap_part(name, c, O)
-            c["oracle_hash"] = oracle_hash()
-            print("restamped", name, flush=True)
+        # an entry only gets the new stamp after its cheap part AND one expensive tile (two more columns of a column entry) have been
+        # re-derived with the oracle as it is now; what was re-derived is recorded in the entry ("restamp_verified")
+        def restamp(item):
+            name, c = item
+            rederive_cheap_part(name, c, O, threads=1 if base_config(name) != "c1" and base_config(name) not in COLUMN_CONFIGS else None)
+            return name, rederive_expensive_part(name, c, O)
+        with ThreadPoolExecutor(max(1, min(args.jobs, len(result)))) as ex:
+            for name, verified in ex.map(restamp, list(result.items())):
+                result[name]["oracle_hash"] = oracle_hash()
+                result[name]["restamp_verified"] = verified
+                print("restamped", name, verified, flush=True)
         json.dump(result, open(args.out, "w"), indent=1)
         return
     for name in args.configs:

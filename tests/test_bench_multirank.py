@@ -75,7 +75,7 @@ def test_bench_gather_only_two_ranks():
 def test_bench_rccl_code_path_world1():
     """The process-group code path of the N>1 launch on the box's REAL RCCL: `torch.distributed.run --nproc-per-node=1 bench.py
     --backend nccl --force-dist` initialises ProcessGroupNCCL with device_id, runs the barriers, the all-reduces (max time, summed
-    segment count) and FilmGather's pack -> dist.gather -> scatter (rank 0's own block included), then compares the gathered film
+    segment count) and FilmGather's render-into-the-send-block -> dist.gather -> k_unpack_tiles (rank 0's own block included), then compares the gathered film
     with a plain single-context render bit for bit.  What a one-GPU box cannot exercise is only the xGMI hop itself."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
@@ -110,11 +110,70 @@ def test_bench_line_contract_n1():
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f32" and out["vs_baseline"] is None
     assert out["value"] > 0 and abs(out["value"] - out["config"]["paths_per_step"] / out["ms_per_step"] / 1e3) < 1e-2 * out["value"]
     rf = out["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["bound"] == "valu" and rf["bound_contract"] in ("hbm", "mfma") and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "k_extend1" in rf["kernel"] or "k_shadow1" in rf["kernel"] or "k_shade_setup" in rf["kernel"]
+    # the flop of an evaluation comes from COUNTED iterations: the MandelBox always runs its 12 folds -> exactly 33 x 12 + 8
+    assert rf["sdf"] == "mandelbox" and rf["flop_per_dist_eval"] == 404.0 and rf["sdf_iterations"] == 12 * rf["dist_evals"]
+    assert 0 < rf["whole_frame"]["frac"] <= rf["frac"] + 1e-9  # the whole frame cannot beat its dominant march kernel
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "tiles" in cb["sample"]
     assert out["cold_ms"] > 0 and out["config"]["build_variant"] == "product" and out["config"]["resolve_kernel"] == "k_resolve_reg<1>"
     assert abs(out["cold_detail"]["context_ms"] + out["cold_detail"]["first_frame_ms"] - out["cold_ms"]) < 0.2
     assert "per_rank" not in out  # single-process line: no process group
     assert all(0 <= v["frac"] < 1.5 for v in out["roofline_hbm"]["kernels"].values())
+
+
+@pytest.mark.gpu
+def test_bench_bulb_prices_the_mandelbulb_by_counted_iterations():
+    """--workload bulb (Mandelbulb extension): the roofline's flop per evaluation comes from the orbit steps the instrumented kernels COUNTED -
+    below the 8 x 84 + 10 = 682 of eight full steps (orbits escape at |w|^2 > 256), above one step."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_ENV_TUNING="1", RAYN_HIP_BATCH_PATHS=str(1 << 22))
+    r = subprocess.run([sys.executable, "-c", "import bench, sys; bench.WORKLOADS['bulb'] = ('bulb', 240, 136, 4, 3, 'small Mandelbulb (test)'); "
+                        "sys.argv = ['bench.py', '--workload', 'bulb', '--steps', '1', '--warmup', '1', '--cpu-seconds', '0', '--no-cold']; bench.main()"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    rf = out["roofline"]
+    assert rf["sdf"] == "mandelbulb" and 84.0 + 10.0 <= rf["flop_per_dist_eval"] < 682.0
+    assert rf["dist_evals"] <= rf["sdf_iterations"] <= 8 * rf["dist_evals"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_self_launch_without_a_launcher(ranks):
+    """`python bench.py --gpus N` with WORLD_SIZE unset relaunches itself under torch.distributed.run (one rank per GPU) instead of exiting:
+    the same single JSON line, the partitioned frame bit-identical to a single-rank render."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_ENV_TUNING="1", RAYN_HIP_BATCH_PATHS=str(1 << 22))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0", "--workload", "c1", "--backend", "gloo",
+           "--share-gpu", "--check-film", "--cpu-seconds", "0", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["film_check"] is True and "relaunching" in r.stderr
+    _check_per_rank(out, ranks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entries", [2, 3])
+def test_bench_single_process_multi_device(entries):
+    """--single-process: ONE process, one rayn_hip_create_multi context over N entries (here all on GPU 0: --share-gpu = device list [0, 0(, 0)]) - the
+    path a rayn host binds for src/film.rs:630-658.  Same JSON line; per-device render times from rayn_hip_get_entry_stats; the film is compared bit for
+    bit with a plain single-device context's."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_ENV_TUNING="1", RAYN_HIP_BATCH_PATHS=str(1 << 22))
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(entries), "--single-process", "--share-gpu", "--steps", "2", "--warmup", "1", "--workload", "c1",
+           "--check-film", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == entries and out["film_check"] is True and "rayn_hip_create_multi" in out["config"]["parallelism"]
+    assert "per_rank" not in out and out["roofline"] is None and out["cpu_baseline"] is None
+    pd = out["per_device"]
+    assert len(pd["render_ms"]) == entries and all(v > 0 for v in pd["render_ms"]) and sum(pd["tiles"]) == 256
+    assert sum(pd["segments"]) == out["segments_per_step"] == json.load(open(os.path.join(ROOT, "tests", "golden", "config_digests.json")))["c1"]["frame_counts"]["segments"]
+    assert max(pd["render_ms"]) <= out["ms_per_step"] * 1.05 + 1.0 and out["exchange_ms"] > -1.0

@@ -4,6 +4,7 @@ No torch.  usage: cold_breakdown.py [workload=shipped] [preinit=0|1]
   preinit=1 calls hipInit / hipGetDeviceCount / hipSetDevice / hipFree(0) through libamdhip64 first and times them separately,
   so that what remains in rayn_hip_create is the library's own share."""
 import ctypes as C
+import os as _os; _os.environ.setdefault("RAYN_HIP_ENV_TUNING", "1")  # the library reads RAYN_HIP_* tuning only under this opt-in (include/rayn_hip.h)
 import os
 import sys
 import time
@@ -17,7 +18,7 @@ from rayn_amd import setup as S  # noqa: E402
 from bench import WORKLOADS  # noqa: E402
 
 scene, W, H, samples, bounces, desc = WORKLOADS[wl]
-cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
+cam, w = S.SCENES[scene]((W, H))
 p = rayn_amd.frame_params(W, H, samples, bounces)
 tabs = rayn_amd.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W, H)
 wd = w.to_desc(cam)

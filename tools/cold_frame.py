@@ -2,15 +2,17 @@
 context, ONE frame through the host-buffer entry (rayn_hip_render_frame).  Prints the cold time (context creation -> film on
 the host), the batches it took, and the following warm frames for comparison.  No torch: this is what a C / Rust host pays.
 usage: cold_frame.py [workload=c2] [cold_bytes] [warm_frames=2]      (cold_bytes 0 = full-size arena up front, the r2 behaviour; -1 = default)
-RAYN_HIP_BATCH_PATHS / RAYN_HIP_WORKERS in the environment select the arena footprint."""
+RAYN_HIP_BATCH_PATHS / RAYN_HIP_WORKERS in the environment select the arena footprint (this script opts in to the library's
+environment tuning itself: RAYN_HIP_ENV_TUNING=1, include/rayn_hip.h - without it the library ignores those names)."""
 import os, sys, time
+os.environ.setdefault("RAYN_HIP_ENV_TUNING", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rayn_amd
 from rayn_amd import setup as S
 from bench import WORKLOADS
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 scene, W, H, samples, bounces, desc = WORKLOADS[wl]
-cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
+cam, w = S.SCENES[scene]((W, H))
 p = rayn_amd.frame_params(W, H, samples, bounces)
 tabs = rayn_amd.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W, H)
 wd = w.to_desc(cam)

@@ -1,12 +1,13 @@
 """PCIe-inclusive rate: rayn_hip_render_frame with HOST buffers (tables H2D + film D2H inside the call) vs the
 device-buffer entry.  usage: host_rate.py [workload=c2]"""
 import sys, time
+import os as _os; _os.environ.setdefault("RAYN_HIP_ENV_TUNING", "1")  # the library reads RAYN_HIP_* tuning only under this opt-in (include/rayn_hip.h)
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, rayn_amd
 from rayn_amd import setup as S
 from bench import WORKLOADS
 scene, W, H, samples, bounces, desc = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
-cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
+cam, w = S.SCENES[scene]((W, H))
 p = rayn_amd.frame_params(W, H, samples, bounces)
 tabs = rayn_amd.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W, H)
 ctx = rayn_amd.Context(0); ctx.upload_world(w.to_desc(cam))

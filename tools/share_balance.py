@@ -2,13 +2,14 @@
 one after the other), i.e. what an N-GPU launch of bench.py would wait for (max over ranks) before the gather.
 usage: share_balance.py <N> [workload=c3]"""
 import os, sys, time
+import os as _os; _os.environ.setdefault("RAYN_HIP_ENV_TUNING", "1")  # the library reads RAYN_HIP_* tuning only under this opt-in (include/rayn_hip.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rayn_amd
 from rayn_amd import setup as S
 from bench import WORKLOADS
 N = int(sys.argv[1]); wl = sys.argv[2] if len(sys.argv) > 2 else "c3"
 scene, W, H, samples, bounces, desc = WORKLOADS[wl]
-cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
+cam, w = S.SCENES[scene]((W, H))
 tabs = rayn_amd.build_tables(4 * samples, bounces, 2, 1, W, H)
 ctx = rayn_amd.Context(0); ctx.upload_world(w.to_desc(cam))
 d = [torch.from_numpy(t).cuda() for t in tabs]

@@ -1,13 +1,14 @@
 """Per-kernel-class times of ONE rank's share of a bench workload.
 usage: share_profile.py <tile_first> <tile_step> [workload=c2]"""
 import os, sys, time
+import os as _os; _os.environ.setdefault("RAYN_HIP_ENV_TUNING", "1")  # the library reads RAYN_HIP_* tuning only under this opt-in (include/rayn_hip.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rayn_amd
 from rayn_amd import setup as S
 from bench import WORKLOADS
 first, step = int(sys.argv[1]), int(sys.argv[2])
 scene, W, H, samples, bounces, desc = WORKLOADS[sys.argv[3] if len(sys.argv) > 3 else "c2"]
-cam, w = {"s0": S.setup_s0, "s1": S.setup_s1, "s2": S.setup_s2, "s3": S.setup_s3, "bulb": S.setup_bulb, "ship": S.setup}[scene]((W, H))
+cam, w = S.SCENES[scene]((W, H))
 p = rayn_amd.frame_params(W, H, samples, bounces, tile_first=first, tile_step=step)
 tabs = rayn_amd.build_tables(4 * samples, bounces, p.volume_marches, p.frame, W, H)
 ctx = rayn_amd.Context(0); ctx.upload_world(w.to_desc(cam))
