@@ -73,3 +73,38 @@ def test_usable_cpus_respects_the_cgroup_quota(monkeypatch, tmp_path):
         return real_open(path, *a, **k)
     monkeypatch.setattr(builtins, "open", fake_open)
     assert bench.usable_cpus() == min(2, os.cpu_count() or 1)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference checkout exists in the build container only")
+@pytest.mark.parametrize("reading,rc,verdict", [
+    ("same", 0, "PINNED: the oracle reproduces rayn bit for bit"),
+    ("tables", 0, "PINNED up to the host tables"),
+    ("normals_order", 1, "IDENTICAL under: normals_order"),
+    ("fma", 1, "IDENTICAL under: fma"),
+])
+def test_pin_script_dry_run_reaches_every_outcome(reading, rc, verdict):
+    """tools/pin_against_rayn.sh end to end without a Rust toolchain (MOCK_RAYN): copy of the REAL checkout, bindings/rayn_dump.patch applied,
+    the three constant edits verified, then the oracle plays rayn under a known reading in rayn's own dump layout (src/dump.rs manifest keys) -
+    and the script must conclude exactly that: pinned at stage 1, pinned at stage 2 (only the host tables differ), or stage 3 naming the reading
+    that is IDENTICAL.  The day a toolchain exists the script cannot fail for script reasons.  (Small frame here; the same run at rayn's
+    shipped 1280x720x8spp is logged in profiles/r05_pin_mock_shipped.txt.)"""
+    env = dict(os.environ, MOCK_RAYN=reading, PYTHON=sys.executable)
+    r = subprocess.run(["sh", os.path.join(ROOT, "tools", "pin_against_rayn.sh"), "/root/reference", "48", "32", "1", "2"], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == rc, r.stdout[-1500:] + r.stderr[-1500:]
+    assert verdict in r.stdout, r.stdout[-1500:]
+    if rc == 1:  # stage 3 went through every reading: exactly one is identical
+        assert r.stdout.count("\nIDENTICAL") == 1 and "== stage 3" in r.stdout
+
+
+def test_pin_script_refuses_a_checkout_it_cannot_edit(tmp_path):
+    """A rayn revision that spells the constants differently must stop the script at the edit check, not later with a size mismatch."""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference checkout needed")
+    import shutil
+    fake = tmp_path / "rayn"
+    shutil.copytree("/root/reference/src", fake / "src")
+    p = fake / "src" / "setup.rs"
+    p.write_text(p.read_text().replace("pub const SAMPLES: usize = 2;", "pub const SAMPLES : usize = 2;"))
+    r = subprocess.run(["sh", os.path.join(ROOT, "tools", "pin_against_rayn.sh"), str(fake), "48", "32", "1", "2"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, MOCK_RAYN="same", PYTHON=sys.executable), cwd="/tmp")
+    assert r.returncode == 4 and "could not set RESOLUTION / SAMPLES / MAX_INDIRECT_BOUNCES" in r.stderr

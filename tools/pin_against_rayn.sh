@@ -5,6 +5,11 @@
 #
 #   tools/pin_against_rayn.sh <rayn checkout> [W H SAMPLES BOUNCES]        defaults: rayn's shipped 1280 720 2 3 (src/setup.rs:16-30)
 #   TILE=<n> (default 1) selects the tile whose per-depth packets are traced; CARGO_FLAGS (default --release); KEEP=1 keeps the work dir
+#   MOCK_RAYN=same|tables|fma|<variant>   dry run WITHOUT a Rust toolchain: every step below runs on the real checkout (copy, patch, the three
+#       constant edits - each verified) EXCEPT `cargo run`, whose dump is written by the oracle playing rayn under that reading
+#       (tools/rayn_dump.py mockrayn).  The outcome is known in advance - same: PINNED at stage 1; tables: PINNED at stage 2; fma / a variant:
+#       stage 3 reports that reading IDENTICAL and the script exits 1 naming it - so the day a toolchain exists the script cannot fail for
+#       script reasons (tests/test_evidence_tools.py runs all three outcomes at a small size; profiles/r05_pin_mock_shipped.txt at rayn's own).
 #
 # Steps: copy the checkout, apply the patch, set RESOLUTION / SAMPLES / MAX_INDIRECT_BOUNCES, `RAYN_DUMP=<dir>,<tile> cargo run`,
 # dump the same frame from the oracle, compare array by array.  If the FILM differs the script goes on by itself:
@@ -16,20 +21,29 @@ set -e
 RAYN=${1:?usage: pin_against_rayn.sh <rayn checkout> [W H SAMPLES BOUNCES]}
 W=${2:-1280}; H=${3:-720}; S=${4:-2}; B=${5:-3}; TILE=${TILE:-1}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-command -v cargo >/dev/null || { echo "cargo not found: this script needs a Rust toolchain" >&2; exit 3; }
+[ -n "$MOCK_RAYN" ] || command -v cargo >/dev/null || { echo "cargo not found: this script needs a Rust toolchain (MOCK_RAYN=<reading> runs every other step without one)" >&2; exit 3; }
 WORK=$(mktemp -d)
 [ -n "$KEEP" ] || trap 'rm -rf "$WORK"' EXIT
 cp -r "$RAYN" "$WORK/rayn"
 cd "$WORK/rayn"
 git apply -p1 "$REPO/bindings/rayn_dump.patch" 2>/dev/null || patch -p1 < "$REPO/bindings/rayn_dump.patch"
+grep -q "^mod dump;" src/main.rs && [ -f src/dump.rs ] || { echo "bindings/rayn_dump.patch did not apply to $RAYN" >&2; exit 4; }
 sed -i "s/pub const RESOLUTION: Extent2u = Extent2u::new([0-9]*, [0-9]*);/pub const RESOLUTION: Extent2u = Extent2u::new($W, $H);/; \
         s/pub const SAMPLES: usize = [0-9]*;/pub const SAMPLES: usize = $S;/; \
         s/pub const MAX_INDIRECT_BOUNCES: usize = [0-9]*;/pub const MAX_INDIRECT_BOUNCES: usize = $B;/" src/setup.rs
+# the three edits must have taken (another rayn revision may spell the constants differently: fail here, not with a size mismatch later)
+grep -q "pub const RESOLUTION: Extent2u = Extent2u::new($W, $H);" src/setup.rs && grep -q "pub const SAMPLES: usize = $S;" src/setup.rs &&
+  grep -q "pub const MAX_INDIRECT_BOUNCES: usize = $B;" src/setup.rs || { echo "could not set RESOLUTION / SAMPLES / MAX_INDIRECT_BOUNCES in src/setup.rs" >&2; exit 4; }
 mkdir -p renders
-RAYN_DUMP="$WORK/dump_rayn,$TILE" cargo run ${CARGO_FLAGS:---release}
 PY=${PYTHON:-python3}
 DUMP="$PY $REPO/tools/rayn_dump.py"
 ARGS="--scene ship --w $W --h $H --samples $S --bounces $B --tile $TILE"
+if [ -n "$MOCK_RAYN" ]; then
+  echo "== MOCK: no cargo run; the oracle writes rayn's dump as '$MOCK_RAYN'"
+  $DUMP mockrayn "$WORK/dump_rayn" --as "$MOCK_RAYN" $ARGS
+else
+  RAYN_DUMP="$WORK/dump_rayn,$TILE" cargo run ${CARGO_FLAGS:---release}
+fi
 echo "== stage 1: oracle (default readings, its own tables) vs rayn"
 $DUMP dump "$WORK/dump_oracle" $ARGS
 if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_oracle"; then echo "PINNED: the oracle reproduces rayn bit for bit on this frame"; exit 0; fi
@@ -37,11 +51,14 @@ echo "== stage 2: the oracle with rayn's own tables (A6 / A7 out of the picture)
 $DUMP dump "$WORK/dump_oracle_t" $ARGS --tables-from "$WORK/dump_rayn"
 if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_oracle_t"; then echo "PINNED up to the host tables: pass rayn's tables to rayn_hip_render_frame (they are plain inputs)"; exit 0; fi
 echo "== stage 3: alternative readings, each with rayn's tables"
+# order = oracle/SENSITIVITY.md's: the readings that move the most pixels first (normals_fast's form, the mul_add policy, dot / normalized, libm, lerp)
+FOUND=""
 $DUMP dump "$WORK/dump_fma" $ARGS --tables-from "$WORK/dump_rayn" --fma 1
-echo "-- fused mul_add (A1)"; $DUMP compare "$WORK/dump_rayn" "$WORK/dump_fma" | tail -6 || true
-for V in minmax_swapped minmax_ieee libm normalize_div dot_plain normals_central normals_order lerp_alt; do
+echo "-- fused mul_add (A1)"; if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_fma" > "$WORK/cmp.txt"; then FOUND="$FOUND fma"; fi; tail -6 "$WORK/cmp.txt"
+for V in normals_order normals_central dot_plain normalize_div libm lerp_alt minmax_swapped minmax_ieee; do
   $DUMP dump "$WORK/dump_$V" $ARGS --tables-from "$WORK/dump_rayn" --variant $V
-  echo "-- $V"; $DUMP compare "$WORK/dump_rayn" "$WORK/dump_$V" | tail -6 || true
+  echo "-- $V"; if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_$V" > "$WORK/cmp.txt"; then FOUND="$FOUND $V"; fi; tail -6 "$WORK/cmp.txt"
 done
-echo "NOT PINNED: see the per-array reports above (work dir: $WORK; re-run with KEEP=1 to keep it)"
+if [ -n "$FOUND" ]; then echo "NOT PINNED under the default readings, but IDENTICAL under:$FOUND - that assumption of oracle/rayn_oracle.cpp is read the other way by rayn"; exit 1; fi
+echo "NOT PINNED: no single alternative reading reproduces rayn; see the per-array reports above (work dir: $WORK; re-run with KEEP=1 to keep it)"
 exit 1

@@ -5,6 +5,11 @@ section 8c "Net", row N2): the only route to ever pin this project's oracle agai
   python tools/rayn_dump.py dump OUT_DIR [--scene s2 --w 64 --h 64 --samples 2 --bounces 3 --tile 1 --backend oracle|gpu]
                                          [--fma 1] [--variant NAME] [--tables-from DIR]
   python tools/rayn_dump.py compare DIR_A DIR_B
+  python tools/rayn_dump.py mockrayn OUT_DIR --as same|tables|fma|<variant> [--scene ship --w .. --h .. --samples .. --bounces .. --tile ..]
+        a STAND-IN for the dump a patched rayn writes (bindings/rayn_dump.patch: src/dump.rs), produced by the oracle so that
+        tools/pin_against_rayn.sh can be run end to end WITHOUT a Rust toolchain (MOCK_RAYN=<as>): same file names, the manifest keys
+        src/dump.rs writes (backend "rayn").  `same` = rayn is the oracle's default reading; `tables` = rayn's sample tables / scramble differ
+        from ours (tables of another frame seed) but its arithmetic is ours; `fma` / <variant> = rayn's arithmetic is that OTHER reading.
 
   --scene ship = the reference's setup::setup() as shipped; --fma 1 = the fused-mul_add oracle (rayn built with +fma);
   --variant NAME = one assumption of the oracle read the other way (oracle/SENSITIVITY.md, oracle_py.VARIANTS);
@@ -70,6 +75,33 @@ def dump(args):
     print(f"wrote {args.out}: {len(arrays) + 1} arrays")
 
 
+def mockrayn(args):
+    """The oracle playing rayn (see the module docstring): what tools/pin_against_rayn.sh must conclude is known in advance for every --as."""
+    from common import case
+    from oracle import oracle_py as O
+    wd, p = case(args.scene, args.w, args.h, args.samples, args.bounces)
+    as_ = args.as_
+    fma = as_ == "fma"
+    variant = as_ if as_ in O.VARIANTS else None
+    assert as_ in ("same", "tables", "fma") or variant, f"--as {as_}: not one of same, tables, fma, {O.VARIANTS}"
+    # rayn's tables are computed by rayn's OWN host code (quasi-rd, SmallRng, its filter): in the mock they come from the default
+    # oracle build, except under `tables`, where they are another frame's (= "A6 / A7 read wrong, arithmetic right")
+    tabs = O.build_tables(4 * args.samples, args.bounces, p.volume_marches, p.frame + (1 if as_ == "tables" else 0), args.w, args.h)
+    film, _ = O.render(wd, p, tabs, fma=fma, variant=variant)
+    trace = O.trace_tile(wd, p, tabs, args.tile, fma=fma, variant=variant)
+    os.makedirs(args.out, exist_ok=True)
+    arrays = dict(zip(F32[:4], tabs))
+    arrays.update({k: film[k] for k in ("color", "alpha", "background", "normal")})
+    for k, a in arrays.items():
+        np.ascontiguousarray(a, np.float32).tofile(os.path.join(args.out, k + ".f32"))
+    np.stack([trace[k] for k in ("depth", "obj", "px", "py", "sample", "valid")], axis=1).astype(np.uint32).tofile(os.path.join(args.out, "trace.u32"))
+    # exactly the keys src/dump.rs::write_manifest writes (bindings/make_patch.py; tests/test_bindings.py keeps the two in step)
+    json.dump({"scene": "rayn setup::setup() [MOCK: the oracle as '%s']" % as_, "width": args.w, "height": args.h, "SAMPLES": args.samples, "spp": 4 * args.samples,
+               "max_bounces": args.bounces, "volume_marches": p.volume_marches, "frame": p.frame, "time_range": [p.time_start, p.time_end],
+               "tile": [p.tile_w, p.tile_h], "trace_tile": args.tile, "backend": "rayn"}, open(os.path.join(args.out, "manifest.json"), "w"), indent=1)
+    print(f"wrote {args.out}: mock rayn dump as '{as_}'")
+
+
 def compare(args):
     ma, mb = (json.load(open(os.path.join(d, "manifest.json"))) for d in (args.a, args.b))
     keys = ("width", "height", "spp", "max_bounces", "volume_marches", "frame")
@@ -115,11 +147,21 @@ def main():
     d.add_argument("--fma", type=int, default=0, choices=[0, 1])
     d.add_argument("--variant", default=None)
     d.add_argument("--tables-from", default=None)
+    m = sub.add_parser("mockrayn")
+    m.add_argument("out")
+    m.add_argument("--as", dest="as_", required=True)
+    for sp, default_scene in ((m, "ship"),):
+        sp.add_argument("--scene", default=default_scene)
+        sp.add_argument("--w", type=int, default=1280)
+        sp.add_argument("--h", type=int, default=720)
+        sp.add_argument("--samples", type=int, default=2)
+        sp.add_argument("--bounces", type=int, default=3)
+        sp.add_argument("--tile", type=int, default=1)
     c = sub.add_parser("compare")
     c.add_argument("a")
     c.add_argument("b")
     args = ap.parse_args()
-    sys.exit(dump(args) if args.cmd == "dump" else compare(args))
+    sys.exit({"dump": dump, "mockrayn": mockrayn, "compare": compare}[args.cmd](args))
 
 
 if __name__ == "__main__":
