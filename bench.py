@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-named", action="store_true", help="default workload only: skip the secondary measurement of the metric's literally named workload (bulb3) reported as `named_workload`")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold first frame through the host-buffer entry (cold_ms)")
     ap.add_argument("--fma-policy", type=int, default=0, choices=[0, 1], help="0: unfused mul_add = rayn's default build (default); 1: fused = rayn built with +fma")
     # test aids for the N>1 path on a box with fewer GPUs than ranks (never used by the driver's launch)
@@ -452,6 +453,32 @@ def main():
                                       f"(restatement of rayn's CPU path; rayn itself cannot be built here), {t_cpu:.1f} s; the GPU renders "
                                       f"{p.tile_w}x{p.tile_h} tiles (same per-path work, different packet grouping)"}
 
+    # BASELINE.json words its metric "1920x1080 Mandelbulb @1024spp".  The reference has no Mandelbulb, so `value` is measured on the reference's own
+    # fractal at that size (c3); the literally named workload - the Mandelbulb EXTENSION with the same volume, same size, same tables - is measured right after,
+    # on the same context, OUTSIDE the timed region, and reported beside it (one warm-up + two timed frames, ~30 s).  `--workload bulb3` gives it a full line.
+    named = None
+    if rank == 0 and world == 1 and n_devices == 1 and args.workload == "c3" and not args.no_named and not args.no_roofline:
+        try:
+            scene_b, Wb, Hb, samples_b, bounces_b, desc_b = WORKLOADS["bulb3"]
+            assert (Wb, Hb, samples_b, bounces_b) == (W, H, samples, bounces)  # same frame parameters and sample tables
+            cam_b, wld_b = S.SCENES[scene_b]((Wb, Hb))
+            ctx.upload_world(wld_b.to_desc(cam_b))
+            ctx.render_device(p, d_tabs, film)
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            for _ in range(2):
+                ctx.render_device(p, d_tabs, film)
+            torch.cuda.synchronize()
+            dt_b = (time.perf_counter() - t_b) / 2
+            st_b = ctx.stats()
+            named = {"workload": desc_b, "value": round(paths_per_step / dt_b / 1e6, 3), "unit": "Mpath-samples/s", "ms_per_step": round(dt_b * 1e3, 3), "steps": 2, "warmup": 1,
+                     "segments_per_step": st_b["segments"],
+                     "note": "secondary measurement on the same context after the timed region of `value`; parity of this workload: tests/test_config_digests.py [bulb3]; "
+                             "its own roofline / cpu_baseline: python bench.py --workload bulb3 (profiles/r05_bench_bulb3_*.json)"}
+            ctx.upload_world(wd)
+        except Exception as e:  # never lose the main line to the secondary measurement
+            named = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         out = {
             "metric": "Mpath-samples/sec", "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world * n_devices, "steps": args.steps,
@@ -471,6 +498,8 @@ def main():
         out["config"]["resolve_kernel"] = ("k_resolve_reg<%d>" % max(1, 1 << max(0, (spp - 1).bit_length() - 6)) if spp <= 512 else
                                            "k_resolve_blk<128, 8>" if spp <= 1024 else "k_resolve_blk<256, 8>" if spp <= 2048 else
                                            "k_resolve_blk<512, 8>" if spp <= 4096 else "k_resolve_huge")
+        if named is not None:
+            out["named_workload"] = named
         if cold_detail is not None:
             out["cold_detail"] = cold_detail
         if per_rank is not None:

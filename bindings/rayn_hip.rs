@@ -185,6 +185,8 @@ extern "C" {
         out_normal: *mut f32,
     ) -> i32;
     pub fn rayn_hip_get_stats(ctx: *const RaynCtx, out: *mut RaynStats) -> i32;
+    /// entry 0 .. rayn_hip_device_count() - 1 of a multi-device context: what THAT device did in the last frame
+    pub fn rayn_hip_get_entry_stats(ctx: *const RaynCtx, entry: i32, out: *mut RaynStats) -> i32;
     pub fn rayn_hip_set_fma_policy(ctx: *mut RaynCtx, policy: i32) -> i32;
     pub fn rayn_hip_sizeof(which: i32) -> usize;
 }

@@ -288,6 +288,13 @@ class Film {
         progressive_epoch++;
     }
     rayn_stats stats() const { rayn_stats s; rayn_hip_get_stats(ctx_, &s); return s; }
+    // what GPU `entry` of a multi-device film did in the last frame (its tiles / segments / its own HIP-event time): rayn_hip_get_entry_stats
+    int device_count() const { return rayn_hip_device_count(ctx_); }
+    rayn_stats device_stats(int entry) const {
+        rayn_stats s;
+        if (rayn_hip_get_entry_stats(ctx_, entry, &s) != RAYN_OK) throw std::runtime_error("rayn_hip_get_entry_stats: no such entry");
+        return s;
+    }
     Extent2u res() const { return res_; }
     rayn_ctx* ctx() { return ctx_; }
 

@@ -120,6 +120,13 @@ class FilmGather:
             return None
         if self.stage_host:
             self.recv_dev.copy_(self.recv_all)
+        if self.ctx is not None:
+            # dist.gather returned once the collective was ENQUEUED (ProcessGroupNCCL makes torch's current stream wait for it, not the
+            # host), and the unpack kernels run on the stream the library is given - its own when torch's current stream is the null
+            # stream.  Wait for the blocks here rather than rely on legacy-null-stream ordering between the two: the frame cannot be
+            # complete before the gather is, so the wait costs nothing that the frame's final synchronise would not pay.
+            import torch
+            torch.cuda.current_stream().synchronize()
         for r in range(0 if self.force else 1, self.world):
             if self.counts[r] == 0:
                 continue

@@ -33,6 +33,16 @@ int main(int argc, char** argv) {
     PathTracingIntegrator integ{(size_t)atoi(argv[5]), 2};
     const float t0 = 1.0f * (1.0f / 24.0f);
     film.render_frame_into(world, cam, integ, BlackmanHarrisFilter::new_(1.5f), Extent2u(16, 16), 1, {t0, t0 + 1.0f / 24.0f}, (size_t)atoi(argv[4]));
+    { // per-device statistics of the one context (rayn_hip_get_entry_stats): every entry rendered tiles, the entries sum to the frame
+        const rayn_stats tot = film.stats();
+        uint64_t paths = 0, segments = 0, tiles = 0;
+        for (int e = 0; e < film.device_count(); e++) {
+            const rayn_stats s = film.device_stats(e);
+            if (s.tiles == 0 || s.ms_total <= 0.0) return 4;
+            paths += s.paths; segments += s.segments; tiles += s.tiles;
+        }
+        if (paths != tot.paths || segments != tot.segments || tiles != tot.tiles || film.device_count() != (n_dev > 0 ? n_dev : 1)) return 5;
+    }
     FILE* f = fopen(argv[7], "wb");
     fwrite(film.color.data(), 4, film.color.size(), f);
     fwrite(film.alpha.data(), 4, film.alpha.size(), f);

@@ -178,3 +178,23 @@ def test_bench_single_process_multi_device(entries):
     assert len(pd["render_ms"]) == entries and all(v > 0 for v in pd["render_ms"]) and sum(pd["tiles"]) == 256
     assert sum(pd["segments"]) == out["segments_per_step"] == json.load(open(os.path.join(ROOT, "tests", "golden", "config_digests.json")))["c1"]["frame_counts"]["segments"]
     assert max(pd["render_ms"]) <= out["ms_per_step"] * 1.05 + 1.0 and out["exchange_ms"] > -1.0
+
+
+@pytest.mark.gpu
+def test_bench_default_line_carries_the_named_workload():
+    """The default workload's line (c3: the reference's fractal at the metric's size) also reports the metric's LITERALLY named workload (bulb3: the
+    Mandelbulb extension, same size / volume / tables), measured on the same context after the timed region.  Both shrunk here to test size."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_ENV_TUNING="1", RAYN_HIP_BATCH_PATHS=str(1 << 22))
+    code = ("import bench, sys; bench.WORKLOADS['c3'] = ('s2', 160, 96, 4, 3, 'small c3 (test)'); bench.WORKLOADS['bulb3'] = ('bulbv', 160, 96, 4, 3, 'small bulb3 (test)'); "
+            "sys.argv = ['bench.py', '--steps', '1', '--warmup', '1', '--cpu-seconds', '0', '--no-cold']; bench.main()")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    nw = out["named_workload"]
+    assert "error" not in nw, nw
+    assert nw["workload"] == "small bulb3 (test)" and nw["value"] > 0 and nw["steps"] == 2 and nw["segments_per_step"] >= out["config"]["paths_per_step"]
+    assert out["config"]["workload"] == "small c3 (test)" and out["roofline"]["sdf"] == "mandelbox"
+    # and the secondary measurement is off where it does not belong
+    code2 = code.replace("'--no-cold']", "'--no-cold', '--no-named']")
+    r2 = subprocess.run([sys.executable, "-c", code2], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "named_workload" not in json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])

@@ -1,6 +1,7 @@
 """Hunt for rare GPU/oracle mismatches: N seeded random scenes (the generator of tests/test_gpu_parity.py's
 test_randomised_scene_parity, larger films, up to 1024 spp).  Every third scene goes through a two-entry multi-device context
-(rayn_hip_create_multi on GPU 0 twice).  usage: fuzz_parity.py [n=60] [first_seed=100]"""
+(rayn_hip_create_multi on GPU 0 twice); r5: every third OTHER scene is rendered share by share (2-5 ranks' shares) straight into the packed planar
+films of the multi-process gather and reassembled with rayn_hip_unpack_share_device.  usage: fuzz_parity.py [n=60] [first_seed=100]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -50,8 +51,27 @@ for seed in range(first, first + n):
     ref, ctr = O.render(wd, p, tabs)
     ctx = ctx2 if seed % 3 == 0 else ctx1
     ctx.upload_world(wd)
-    out = ctx.render_host(p, tabs)
-    st = ctx.stats()
+    if seed % 3 == 1:  # the film gather of a multi-process launch: every rank's share -> its packed film -> one unpack each
+        import copy
+        from rayn_amd.film import share_pixels
+        world_n = int(rng.integers(2, 6))
+        d_tabs = [torch.from_numpy(t).cuda() for t in tabs]
+        film = R.film.alloc_device_film(w, h, "cuda:0")
+        st = {"paths": 0, "segments": 0}
+        for r in range(world_n):
+            pr = copy.copy(p)
+            pr.tile_first, pr.tile_step = r, world_n
+            packed = torch.empty(10 * max(share_pixels(pr), 1), dtype=torch.float32, device="cuda:0")
+            ctx.render_packed(pr, d_tabs, packed)
+            sr = ctx.stats()
+            st["paths"] += sr["paths"]; st["segments"] += sr["segments"]
+            ctx.unpack_share(pr, packed, film)
+        torch.cuda.synchronize()
+        out = {"color": film["color"].cpu().numpy().reshape(h, w, 3), "alpha": film["alpha"].cpu().numpy().reshape(h, w),
+               "background": film["background"].cpu().numpy().reshape(h, w, 3), "normal": film["normal"].cpu().numpy().reshape(h, w, 3)}
+    else:
+        out = ctx.render_host(p, tabs)
+        st = ctx.stats()
     ok = st["paths"] == ctr.paths and st["segments"] == ctr.segments and film_equal_bits(out, ref)
     if not ok:
         bad += 1

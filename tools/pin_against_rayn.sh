@@ -51,11 +51,14 @@ echo "== stage 2: the oracle with rayn's own tables (A6 / A7 out of the picture)
 $DUMP dump "$WORK/dump_oracle_t" $ARGS --tables-from "$WORK/dump_rayn"
 if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_oracle_t"; then echo "PINNED up to the host tables: pass rayn's tables to rayn_hip_render_frame (they are plain inputs)"; exit 0; fi
 echo "== stage 3: alternative readings, each with rayn's tables"
-# order = oracle/SENSITIVITY.md's: the readings that move the most pixels first (normals_fast's form, the mul_add policy, dot / normalized, libm, lerp)
+# order = oracle/SENSITIVITY.md's, shipped frame: the readings that move the most pixels beyond 1e-4 first - the FORM of normals_fast (central differences: 48 %), the
+# mul_add policy (38 %), dot / normalized (32 / 31 %), the tetrahedron's summation order (9 %), libm (0.8 %), lerp (0.3 %); the max / min readings move nothing
 FOUND=""
+$DUMP dump "$WORK/dump_normals_central" $ARGS --tables-from "$WORK/dump_rayn" --variant normals_central
+echo "-- normals_central"; if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_normals_central" > "$WORK/cmp.txt"; then FOUND="$FOUND normals_central"; fi; tail -6 "$WORK/cmp.txt"
 $DUMP dump "$WORK/dump_fma" $ARGS --tables-from "$WORK/dump_rayn" --fma 1
 echo "-- fused mul_add (A1)"; if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_fma" > "$WORK/cmp.txt"; then FOUND="$FOUND fma"; fi; tail -6 "$WORK/cmp.txt"
-for V in normals_order normals_central dot_plain normalize_div libm lerp_alt minmax_swapped minmax_ieee; do
+for V in dot_plain normalize_div normals_order libm lerp_alt minmax_swapped minmax_ieee; do
   $DUMP dump "$WORK/dump_$V" $ARGS --tables-from "$WORK/dump_rayn" --variant $V
   echo "-- $V"; if $DUMP compare "$WORK/dump_rayn" "$WORK/dump_$V" > "$WORK/cmp.txt"; then FOUND="$FOUND $V"; fi; tail -6 "$WORK/cmp.txt"
 done
