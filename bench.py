@@ -193,7 +193,13 @@ def main():
     ctx.set_fma_policy(args.fma_policy)
     cold_ms = None
     cold_detail = None
-    if not use_dist and not args.no_cold and n_devices == 1:
+    measure_cold = not use_dist and not args.no_cold and n_devices == 1
+    if not measure_cold:
+        # no cold frame is measured (N > 1, --single-process, --no-cold): the context's FIRST frame is then the first warm-up frame, and the library's first-frame
+        # policy (small arenas for hosts that render one frame per process, rayn_hip_set_cold_bytes) would move the one-off growth of the arenas into the SECOND
+        # frame - the first timed step at --warmup 1.  Full-size arenas at once: every one-off cost lands in the warm-up.
+        ctx.set_cold_bytes(0)
+    if measure_cold:
         t_created = time.perf_counter()
         ctx.render_host(p, tabs)
         cold_ms = (time.perf_counter() - t_cold) * 1e3
