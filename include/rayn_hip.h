@@ -182,7 +182,7 @@ typedef struct {
     uint64_t queue_bytes_bin;     /* algorithmic HBM bytes of the bin stage */
     double ms_shadow, ms_finish; /* k_shadow, k_shade_finish */
     uint64_t queue_bytes_compact; /* algorithmic HBM bytes of the repack stage */
-    uint64_t shadow_jobs;         /* shadow segments marched by k_shadow (37 algorithmic bytes each: 4 ref + 32 segment in, 1 visibility out) */
+    uint64_t shadow_jobs;         /* shadow segments marched by k_shadow (29 algorithmic bytes each: 4 ref + 24 segment in, 1 visibility out) */
 } rayn_stats;
 
 typedef struct rayn_ctx rayn_ctx;
@@ -246,7 +246,8 @@ int rayn_hip_get_entry_stats(const rayn_ctx* ctx, int entry, rayn_stats* out);
  * floats for the N = rayn_share_pixels(p) pixels of its tiles, tile after tile in ascending reference tile order, pixel-major (x outer,
  * y inner) inside a tile.  That buffer is what crosses xGMI (ONE ncclGather / peer copy); the receiving rank scatters it into its
  * full-resolution film with rayn_hip_unpack_share_device (p carrying the SENDER's tile_first / tile_step): one kernel launch,
- * enqueued on hip_stream and not waited for; the share's tile list is uploaded the first time a share is seen and cached in the ctx.
+ * enqueued on hip_stream and not waited for; the share's tile list is uploaded the first time a share is seen and cached in the ctx for its
+ * lifetime (one list of <= 32 B per tile per distinct (resolution, tile size, tile_first, tile_step): a fixed partition costs N - 1 lists).
  * It is the same packed layout and the same two kernels rayn_hip_create_multi uses between the devices of one process. */
 uint64_t rayn_share_pixels(const rayn_frame_params* p);
 int rayn_hip_render_frame_packed_device(rayn_ctx* ctx, const rayn_frame_params* p,

@@ -140,10 +140,11 @@ def test_bench_bulb_prices_the_mandelbulb_by_counted_iterations():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_bench_self_launch_without_a_launcher(ranks):
     """`python bench.py --gpus N` with WORLD_SIZE unset relaunches itself under torch.distributed.run (one rank per GPU) instead of exiting:
-    the same single JSON line, the partitioned frame bit-identical to a single-rank render."""
+    the same single JSON line, the partitioned frame bit-identical to a single-rank render.  ranks = 8 is the driver's largest launch (here all
+    eight share the one GPU over gloo: the partition, the eight packed blocks and rank 0's seven unpack launches are the real ones)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", RAYN_HIP_ENV_TUNING="1", RAYN_HIP_BATCH_PATHS=str(1 << 22))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0", "--workload", "c1", "--backend", "gloo",
