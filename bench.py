@@ -450,7 +450,7 @@ def main():
                                       f"{threads} threads, one tile per task like the reference's rayon pool, {t_w:.1f} s"}
         else:
             t_cal, paths_cal, k_cal = run(threads)
-            rounds = int(min(32, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))
+            rounds = int(min(128, max(3, round(args.cpu_seconds / max(t_cal, 1e-3)))))  # r5: cap 32 -> 128 rounds (a c3 sample stopped at 4.7 s of the 15 s it is given)
             k = int(min(n_tiles, threads * rounds))
             t_cpu, paths_cpu, k_used = run(k)
             cpu_baseline = {"value": round(paths_cpu / t_cpu / 1e6, 4), "unit": "Mpath-samples/s", "cores": threads, "host_threads_visible": os.cpu_count(), "kind": "port",
