@@ -45,14 +45,14 @@ def test_pmc_join_and_json(tmp_path):
 def test_committed_pmc_files_match_the_kernel_sources():
     sys.path.insert(0, ROOT)
     from bench import kernel_source_hash
-    for wl in ("c3", "c2"):
+    for wl in ("c3", "c2", "bulb3"):
         path = os.path.join(ROOT, "profiles", f"r05_pmc_hbm_{wl}.json")
         if not os.path.exists(path):
             pytest.skip(f"{path} not collected yet (tools/gpu_round.sh)")
         j = json.load(open(path))
         if j["source_hash"] != kernel_source_hash():  # legitimate while kernels are being changed: bench.py then quotes no traffic
             pytest.skip(f"profiles/r05_pmc_hbm_{wl}.json was measured on other kernel sources: re-run tools/passes_r05/gpu_round_r05.sh before the round ends")
-        dom = j["kernels"]["k_shadow1" if wl == "c3" else "k_extend1"]
+        dom = j["kernels"]["k_extend1" if wl == "c2" else "k_shadow1"]
         assert dom["hbm_bytes_per_launch"] > 0 and 0.2 < dom["valu_inst_per_cycle_simd"] <= 0.5 and 0.5 < dom["lanes_enabled"] <= 1.0
 
 
