@@ -291,6 +291,11 @@ int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]);
  * the Mandelbulb extension stops at its bailout; a sphere SDF has none): what an evaluation of the scene's own SDF costs is
  * flop_per_iteration * iterations / evaluations + the epilogue - bench.py prices the roofline with it instead of a fixed figure */
 int rayn_hip_get_sdf_iterations(const rayn_ctx* ctx, uint64_t out[3]);
+/* r6, same instrumented kernels: out[0] = shaded slots whose throughput was exactly (0, 0, 0) and whose NEE was therefore elided - every Le / surface / volume
+ * NEE term of src/integrator.rs:70,91-92,128-129 is multiplied by that zero, so their shadow rays are never marched (k_shade_setup, exact: see the
+ * kernel) - out[1] = the shadow segments those slots would have parked for TracedSDF::occluded (src/sdf.rs:25-57), out[2] = NEE samples of such
+ * slots that were NOT elided because their contribution is not provably finite (then inf * 0 / NaN must keep its bits: tested and marched as ever) */
+int rayn_hip_get_elision_counts(const rayn_ctx* ctx, uint64_t out[3]);
 /* A frame's tiles are dealt to up to two workers (host thread + HIP stream + own device memory each) so that one
  * worker's HBM-bound kernels and readbacks run underneath the other's VALU-bound marches.  n_workers 1..4 (default 2).
  * A further worker is only used while every worker still gets full-size batches and the call owns >= min_paths camera

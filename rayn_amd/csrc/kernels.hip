@@ -734,14 +734,27 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
         receives = sc.m[h.material].receives_light != 0;
         rad = rad + bsdf_le(sc.m[h.material], -d) * thr * vol_T;
         pool.col0[P] = make_float4(rad.x, rad.y, rad.z, c0.w); // throughput.r stays: k_shade_finish needs the old one
-        nee.T[j] = vol_T;
     }
     const DMaterial& mat = sc.m[sc.h[obj].material];
     const f3 wo = -d;
+    // ---- r6: segments whose throughput is EXACTLY (0, 0, 0) ------------------------------------------------------------------------
+    // DielectricBSDF::scatter zeroes f when the picked specular lobe lands below the horizon (src/material.rs:240-243) and roulette cannot
+    // end a path before depth 3 (src/integrator.rs:147-156), so 9 % of the shaded segments of config 3 (24 % at depth 2, 33 % at depth 3;
+    // zero is absorbing: 0 * f stays 0, a NaN product keeps the old throughput, src/integrator.rs:181) arrive with throughput 0.  Every NEE
+    // term of such a segment is   rad + ((x * occluded) / pdf) * thr * corr * (vol_T | rho_s * aux)   (src/integrator.rs:91-92,128-129):
+    // with |x| <= 2^60 and pdf >= 2^-60 (or +inf) the quotient is FINITE for occluded = 0 and for 1, finite * (+-0) is +-0, it stays +-0
+    // through the finite factors that follow, and rad + (+-0) == rad bit for bit (rad is never -0: it starts at +0 and a sum is -0 only
+    // when both terms are).  The visibility of such a sample cannot reach the film: no sphere tests, no parked segment, no shadow march
+    // (vis stays 1; k_shade_finish adds its exact zero).  The path itself goes on: its hit object still decides packet membership
+    // (src/hitable.rs:100-133).  A sample outside the bounds (NaN, overflow: a degenerate half vector, a light of absurd power) is tested
+    // and marched as before, so inf * 0 / NaN cases keep their bits (FILM case "huge_lights").
+    constexpr float ELIDE_MAX_X = 1.1529215e18f /* 2^60 */, ELIDE_MIN_PDF = 8.6736174e-19f /* 2^-60 */, FINITE_MAX = 3.40282347e+38f;
+    const bool zero_w = valid && all_zero(thr) && __builtin_fabsf(vol_T) <= FINITE_MAX && __builtin_fabsf(sc.rho_s) <= FINITE_MAX;
+    uint32_t n_elided_jobs = 0, n_oob = 0; // COUNT builds only: the shadow segments the elision did not park; samples of zero-weight slots outside the bounds
     // ---- surface NEE, surface_sample_one_light src/integrator.rs:207-240
     const bool do_surf = valid && receives && nl > 0;
     {
-        if (do_surf) flags |= 2u;
+        if (do_surf) { flags |= 2u; nee.T[j] = vol_T; }
         for (uint32_t i = 0; i < 4; i++) {
             if (!do_surf) nee.vis[i * cap + j] = 1; // nothing pending for this (sample, slot)
             else {
@@ -767,7 +780,9 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
                 nee.pdf[i * cap + j] = pdf;
                 uint8_t vis = 1;
                 // x == 0 (light below the horizon): (x*occluded)/pdf is the same zero for occluded 0 or 1 -> no test needed
-                if (!all_zero(x)) {
+                const bool zw = zero_w && __builtin_fabsf(x.x) <= ELIDE_MAX_X && __builtin_fabsf(x.y) <= ELIDE_MAX_X && __builtin_fabsf(x.z) <= ELIDE_MAX_X && pdf >= ELIDE_MIN_PDF;
+                if (COUNT) { if (zw && !all_zero(x) && scene_has_sdf && spheres_visible(occlude_point, end_point)) n_elided_jobs++; if (zero_w && !zw) n_oob++; }
+                if (!all_zero(x) && !zw) {
                     if (!spheres_visible(occlude_point, end_point)) vis = 0;
                     else if (scene_has_sdf) { vis = 2; park_job(i, occlude_point, end_point); }
                 }
@@ -819,14 +834,18 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
                     f3 end_point; float lpdf;
                     light_sample(L, u0, u1, sp, &end_point, &lpdf);
                     float dl = mag(end_point - sp);
-                    float f = 1.0f / (4.0f * PI_F);
                     float tr = sc.has_extinct ? dmf_expf(-sc.rho_t * dl) : 1.0f;
-                    (void)f; // x = L.emission * f * tr is rebuilt by k_shade_finish from the light index and tr (same operations, same bits)
+                    // x = L.emission * f * tr is rebuilt by k_shade_finish from the light index and tr (same operations, same bits)
                     nee.vtr[(s - 4) * cap + j] = tr;
                     nee.pdf[s * cap + j] = vpdf * lpdf;
                     nee.aux[(s - 4) * cap + j] = vaux;
                     uint8_t vis = 1;
-                    if (!spheres_visible(sp, end_point)) vis = 0;
+                    // zero-weight slot (see above): x = Le * (1/(4 pi) * tr) with the constant factor <= 1 and tr the only variable, pdf = vpdf * lpdf, then * rho_s * aux
+                    const bool zw = zero_w && __builtin_fabsf(L.emission.x * tr) <= ELIDE_MAX_X && __builtin_fabsf(L.emission.y * tr) <= ELIDE_MAX_X &&
+                                    __builtin_fabsf(L.emission.z * tr) <= ELIDE_MAX_X && vpdf * lpdf >= ELIDE_MIN_PDF && __builtin_fabsf(vaux) <= FINITE_MAX;
+                    if (COUNT) { if (zw && scene_has_sdf && spheres_visible(sp, end_point)) n_elided_jobs++; if (zero_w && !zw) n_oob++; }
+                    if (zw) {}
+                    else if (!spheres_visible(sp, end_point)) vis = 0;
                     else if (scene_has_sdf) { vis = 2; park_job(s, sp, end_point); }
                     nee.vis[s * cap + j] = vis;
                 }
@@ -871,6 +890,15 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
     const uint64_t m = __ballot(is_alive); // the group's survivors: count for the repack scan, mask for the scatter's ranks
     if (lane == 0) { alive_mask[j >> 6] = m; bgrp_cnt[j >> 6] = (uint8_t)__popcll(m); }
     if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
+    if (COUNT) { // elision accounting: [3] zero-weight slots, [7] shadow segments they would have parked, [8] their samples outside the bounds (evals_out = &evals[1])
+        const uint64_t em = __ballot(zero_w);
+        uint32_t nj = n_elided_jobs, no = n_oob;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { nj += (uint32_t)__shfl_xor((int)nj, off); no += (uint32_t)__shfl_xor((int)no, off); }
+        if (lane == 0 && em) {
+            atomicAdd(evals_out + 2, (unsigned long long)__popcll(em)); atomicAdd(evals_out + 6, (unsigned long long)nj); atomicAdd(evals_out + 7, (unsigned long long)no);
+        }
+    }
 }
 
 // Dense list of the pending (sample, slot) pairs.  A block scans 256 * SCAN_ITEMS ids per trip; each wave takes whole 64-id groups

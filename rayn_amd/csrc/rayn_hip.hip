@@ -52,13 +52,13 @@ struct Worker {
     uint32_t* h_totals = nullptr;          // pinned
     DCtl* h_ctl = nullptr;                 // pinned: the control block read back once per frame share
     std::vector<DTile> h_tiles;            // staging of every batch's tile list (one upload per frame share)
-    unsigned long long* d_evals = nullptr; // [8]: SDF evaluations of extend / shade setup / shadow in [0..2], the fold / orbit iterations they ran in [4..6]
+    unsigned long long* d_evals = nullptr; // [16]: SDF evaluations of extend / shade setup / shadow in [0..2], the fold / orbit iterations they ran in [4..6]; elision accounting of k_shade_setup in [3], [7], [8]
     DCtl* d_ctl = nullptr;                 // device control block (outside the arena: the arena may be re-allocated between frames)
     hipEvent_t done = nullptr;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
     rayn_stats stats;
-    unsigned long long evals[3] = {0, 0, 0}, iters[3] = {0, 0, 0};
+    unsigned long long evals[3] = {0, 0, 0}, iters[3] = {0, 0, 0}, elided[3] = {0, 0, 0};
     std::string err;
     int rc = 0;
 };
@@ -78,6 +78,7 @@ struct rayn_ctx {
     rayn_stats stats;
     unsigned long long evals[3] = {0, 0, 0}; // extend, shade_setup (normals), shadow
     unsigned long long iters[3] = {0, 0, 0}; // fold / orbit iterations of those evaluations (instrumented kernels only)
+    unsigned long long elided[3] = {0, 0, 0}; // zero-throughput slots, shadow segments they would have parked, their samples that took the ordinary path (instrumented kernels only)
     bool profiling = false, counting = false;
     size_t batch_paths = (size_t)1 << 28;   // per worker; also limited by the HBM budget and the 32-bit job refs (render_device)
     size_t two_worker_min_paths = (size_t)1 << 22;
@@ -265,7 +266,7 @@ hipEvent_t get_event(Worker* w) {
 int ensure_worker(rayn_ctx* ctx, Worker* w, bool own_stream) {
     bool ok = hipSetDevice(ctx->device) == hipSuccess;
     if (ok && !w->d_ctl)
-        ok = hipMalloc((void**)&w->d_evals, 64) == hipSuccess && hipMalloc((void**)&w->d_ctl, sizeof(DCtl)) == hipSuccess &&
+        ok = hipMalloc((void**)&w->d_evals, 128) == hipSuccess && hipMalloc((void**)&w->d_ctl, sizeof(DCtl)) == hipSuccess &&
              hipHostMalloc((void**)&w->h_totals, 16) == hipSuccess && hipHostMalloc((void**)&w->h_ctl, sizeof(DCtl)) == hipSuccess &&
              hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess;
     if (ok && own_stream && !w->own) ok = hipStreamCreateWithFlags(&w->own, hipStreamNonBlocking) == hipSuccess;
@@ -313,6 +314,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     memset(&w->stats, 0, sizeof w->stats);
     w->evals[0] = w->evals[1] = w->evals[2] = 0;
     w->iters[0] = w->iters[1] = w->iters[2] = 0;
+    w->elided[0] = w->elided[1] = w->elided[2] = 0;
     if (mine.empty()) return 0;
     WCHK(hipSetDevice(ctx->device));
     const DScene& hs = F.hs;
@@ -415,7 +417,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     w->h_tiles.clear();
     w->h_tiles.reserve(total_tiles);
     WCHK(hipMemsetAsync(d_ctl, 0, sizeof(DCtl), stream));
-    WCHK(hipMemsetAsync(w->d_evals, 0, 64, stream));
+    WCHK(hipMemsetAsync(w->d_evals, 0, 128, stream));
     const bool count = F.count, prof = F.profiling;
     const Tables& tab = F.tab;
     const uint32_t last_depth = F.p->max_bounces; // a path that reaches depth == max_bounces terminates there (src/integrator.rs:171)
@@ -532,9 +534,10 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
         w->stats.queue_bytes_compact = c.shaded_slots * 4 + c.next_sum * 4 + (c.shaded_slots / 64) * 17;
     }
     if (count) {
-        unsigned long long h[8];
-        WCHK(hipMemcpy(h, w->d_evals, 64, hipMemcpyDeviceToHost));
+        unsigned long long h[16];
+        WCHK(hipMemcpy(h, w->d_evals, 128, hipMemcpyDeviceToHost));
         for (int k = 0; k < 3; k++) { w->evals[k] = h[k]; w->iters[k] = h[4 + k]; }
+        w->elided[0] = h[3]; w->elided[1] = h[7]; w->elided[2] = h[8];
     }
     return 0;
 }
@@ -575,6 +578,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
     ctx->iters[0] = ctx->iters[1] = ctx->iters[2] = 0;
+    ctx->elided[0] = ctx->elided[1] = ctx->elided[2] = 0;
     ctx->trace.clear();
     if (owned.empty()) return RAYN_OK;
 
@@ -669,6 +673,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         ctx->stats.queue_bytes_bin += w.stats.queue_bytes_bin; ctx->stats.queue_bytes_compact += w.stats.queue_bytes_compact;
         ctx->stats.shadow_jobs += w.stats.shadow_jobs;
         for (int k = 0; k < 3; k++) { ctx->evals[k] += w.evals[k]; ctx->iters[k] += w.iters[k]; }
+        for (int k = 0; k < 3; k++) ctx->elided[k] += w.elided[k];
     }
     HIPCHK(hipEventRecord(ctx->ev_b, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -824,6 +829,7 @@ int render_multi(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, c
         total.ms_raygen += s.ms_raygen; total.ms_extend += s.ms_extend; total.ms_bin += s.ms_bin; total.ms_shade += s.ms_shade; total.ms_compact += s.ms_compact;
         total.ms_resolve += s.ms_resolve; total.ms_shadow += s.ms_shadow; total.ms_finish += s.ms_finish;
         for (int k = 0; k < 3; k++) { ctx->evals[k] += c->evals[k]; ctx->iters[k] += c->iters[k]; }
+        for (int k = 0; k < 3; k++) ctx->elided[k] += c->elided[k];
     }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev_ma, ctx->ev_mb);
@@ -1123,6 +1129,11 @@ int rayn_hip_get_eval_counts(const rayn_ctx* ctx, uint64_t out[3]) {
 int rayn_hip_get_sdf_iterations(const rayn_ctx* ctx, uint64_t out[3]) {
     if (!ctx || !out) return RAYN_ERR_INVALID_ARG;
     for (int i = 0; i < 3; i++) out[i] = ctx->iters[i];
+    return RAYN_OK;
+}
+int rayn_hip_get_elision_counts(const rayn_ctx* ctx, uint64_t out[3]) {
+    if (!ctx || !out) return RAYN_ERR_INVALID_ARG;
+    for (int k = 0; k < 3; k++) out[k] = ctx->elided[k];
     return RAYN_OK;
 }
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths) {

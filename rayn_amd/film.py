@@ -135,6 +135,13 @@ class Context:
         self._chk(self._L.rayn_hip_get_sdf_iterations(self.h, out))
         return {"extend": out[0], "shade_setup": out[1], "shadow": out[2]}
 
+    def elision_counts(self):
+        """Instrumented kernels (rayn_hip_get_elision_counts): shaded slots with throughput exactly (0, 0, 0) whose NEE was elided, and the
+        shadow segments they would have parked."""
+        out = (C.c_uint64 * 3)()
+        self._chk(self._L.rayn_hip_get_elision_counts(self.h, out))
+        return {"zero_throughput_slots": out[0], "elided_shadow_jobs": out[1], "samples_out_of_bounds": out[2]}
+
     def render_host(self, params, tables, out=None):
         """rayn_hip_render_frame with host (numpy) buffers.  Returns the film dict."""
         s1, s2, scr, fis = tables

@@ -108,5 +108,20 @@ def setup_s3(resolution=(7680, 4320), moving_fractal=True):
     return camera, world
 
 
+def setup_bulb5(resolution=(7680, 4320)):
+    """EXTENSION scene of BASELINE configs[4] as literally named ("animated Mandelbulb with time-sampled motion blur"): the
+    Mandelbulb scene (volumes off) seen by S3's moving camera (reference-supported closure, src/animation.rs:55-68) while the bulb
+    itself translates during the shutter (TracedSDF.transform_seq extension -> rayn_hitable.center_vel).  Nothing in rayn
+    corresponds: its only fractal is the MandelBox (src/sdf.rs:104-141) and its TracedSDF ignores time (src/sdf.rs:25,59)."""
+    from .scene import Linear
+    camera, world = setup(resolution, volumes=False, sdf="mandelbulb")
+    cam = world.cameras.get(camera)
+    cam.origin = Linear(cam.origin, vec3(0.54, -0.18, 0.09))  # S3's camera drift scaled by the bulb scene's shorter camera distance (1.35 / 2.25)
+    for h in world.hitables:
+        if isinstance(h, TracedSDF):
+            h.transform_seq = Linear(vec3(0.0, 0.0, 0.0), vec3(-0.36, 0.27, 0.18))
+    return camera, world
+
+
 # scene tag -> constructor (bench.py WORKLOADS, tests/golden/make_config_digests.py CONFIGS, tools/): "ship" = setup::setup() as shipped
-SCENES = {"s0": setup_s0, "s1": setup_s1, "s2": setup_s2, "s3": setup_s3, "bulb": setup_bulb, "bulbv": setup_bulb3, "ship": setup}
+SCENES = {"s0": setup_s0, "s1": setup_s1, "s2": setup_s2, "s3": setup_s3, "bulb": setup_bulb, "bulbv": setup_bulb3, "bulbm": setup_bulb5, "ship": setup}

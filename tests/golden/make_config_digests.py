@@ -9,6 +9,7 @@ different computation from the 4x4-tile cases of FILM_CASES.  This script runs t
     c3: 1920x1080,  1024 spp,  8 bounces, MandelBox + homogeneous volume   (the bench default)
     c4: 3840x2160,  1024 spp, 12 bounces, MandelBox
     c5: 7680x4320,  4096 spp, 16 bounces, MandelBox, moving camera + moving fractal (time-sampled motion blur)
+    bulb / bulb3 / bulb4 / bulb5: the sizes of c2 / c3 / c4 / c5 with the power-8 Mandelbulb EXTENSION (the fractal BASELINE.json names)
     c1_fma, c3_fma: the same tiles as c1 / c3 with FUSED mul_add (librayn_oracle_fma.so = rayn built with +fma)
 
 at FULL resolution and tile size, and writes per tile: the path / segment / packet / SDF-evaluation counts and one
@@ -54,6 +55,12 @@ CONFIGS = {
     # 1024 spp, 8 bounces, Mandelbulb + homogeneous volume (rho_s 0.25, rho_t 0.035).  The reference has no Mandelbulb (src/sdf.rs:104-141 is
     # its only fractal), so nothing in rayn corresponds to these digests: they pin the HIP path to the oracle's restated extension.
     "bulb3": ("bulbv", 1920, 1080, 256, 8),
+    # BASELINE configs[3] / configs[4] WITH THE FRACTAL THEY NAME: "3840x2160, 1024 spp, 12 bounces, Mandelbulb SDF" and
+    # "7680x4320, 4096 spp, 16 bounces, animated Mandelbulb with time-sampled motion blur" (moving camera + the bulb translating through
+    # rayn_hitable.center_vel).  Nothing in rayn corresponds to either: its only fractal is the MandelBox (src/sdf.rs:104-141) and its TracedSDF
+    # ignores time (src/sdf.rs:25,59) - c4 / c5 above are these sizes on the reference's own fractal.
+    "bulb4": ("bulb", 3840, 2160, 256, 12),
+    "bulb5": ("bulbm", 7680, 4320, 1024, 16),
     # the reference's OWN workload: src/main.rs:47-82 (1280x720, SAMPLES = 2 -> 8 spp, 3 bounces, frame 1, 16x16 tiles) on
     # src/setup.rs:46-170 as shipped (volumes on) - the WHOLE frame (3 600 tiles, 7.37 M paths)
     "shipped": ("ship", 1280, 720, 2, 3),
@@ -64,6 +71,12 @@ FMA_CONFIGS = {"c1_fma": "c1", "c3_fma": "c3", "shipped_fma": "shipped"}
 # src/film.rs:399-427, so a column is a run of consecutive tiles) + one digest of the whole film
 COLUMN_CONFIGS = ("shipped",)
 CHANNELS = ("color", "alpha", "background", "normal")
+# 8K entries: an oracle call allocates a 1.3 GB film, so few run at a time and the CPU test leaves their re-derivation to the GPU test
+BIG_FILM_CONFIGS = ("c5", "bulb5")
+# entries of an EXTENSION scene carry this note (the test asserts it)
+EXTENSION_NOTE = ("EXTENSION: nothing in rayn corresponds to these digests - its only fractal is the MandelBox (src/sdf.rs:104-141) and its TracedSDF "
+                  "ignores time (src/sdf.rs:25,59); they pin the HIP path to the oracle's restated Mandelbulb at this BASELINE size")
+EXTENSION_CONFIGS = ("bulb", "bulb3", "bulb4", "bulb5")
 
 
 def _code_only(text):
@@ -197,7 +210,7 @@ def rederive_cheap_part(name, c, O, threads=None):
         film, ctr = O.render(wd, p, tabs, fma=fma, threads=threads, tile_subset=list(range(tx * ny, tx * ny + ny)))
         assert ctr.tiles == ny
         assert rect_digests(film, col["x"][0], 0, col["x"][1], p.height) == col["sha256"], (name, tx)
-    elif base_config(name) != "c5":  # a c5 oracle call allocates a 1.3 GB film: left to the GPU test
+    elif base_config(name) not in BIG_FILM_CONFIGS:  # an 8K oracle call allocates a 1.3 GB film: left to the GPU test
         t = min(c["tiles"], key=lambda t: (t["segments"], t["paths"]))
         film, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[t["tile"]], fma=fma)
         assert (ctr.paths, ctr.segments) == (t["paths"], t["segments"])
@@ -223,7 +236,7 @@ def rederive_expensive_part(name, c, O, jobs=1):
             assert rect_digests(film, col["x"][0], 0, col["x"][1], p.height) == col["sha256"], (name, tx)
         return {"columns": [col["column"] for col in cols]}
     ranked = sorted(c["tiles"], key=lambda t: t["segments"])
-    t = ranked[len(ranked) // 2] if base == "c5" else ranked[-1]
+    t = ranked[len(ranked) // 2] if base in BIG_FILM_CONFIGS else ranked[-1]
     film, ctr = O.render(wd, p, tabs, threads=1, tile_subset=[t["tile"]], fma=fma)
     assert (ctr.paths, ctr.segments, ctr.dist_evals) == (t["paths"], t["segments"], t["dist_evals"]), (name, t["tile"])
     assert tile_digests(film, p, t["tile"]) == t["sha256"], (name, t["tile"])
@@ -286,13 +299,15 @@ def main():
             return {"tile": k, "rect": [x0, y0, x1, y1], "paths": ctr.paths, "segments": ctr.segments, "packets": ctr.packets,
                     "dist_evals": ctr.dist_evals, "alpha_mean": float(film["alpha"][y0:y1, x0:x1].mean()), "sha256": tile_digests(film, p, k)}
 
-        with ThreadPoolExecutor(min(args.jobs, 4 if name == "c5" else args.jobs)) as ex:  # c5: 1.3 GB of film per oracle call
+        with ThreadPoolExecutor(min(args.jobs, 4 if name in BIG_FILM_CONFIGS else args.jobs)) as ex:  # 8K: 1.3 GB of film per oracle call
             recs = list(ex.map(run, tiles))
         scene, W, H, smp, bounces = CONFIGS[base_config(name)]
         result[name] = {"scene": scene, "width": W, "height": H, "samples": smp, "spp": 4 * smp, "max_bounces": bounces,
                         "volume_marches": p.volume_marches, "frame": p.frame, "tile": [p.tile_w, p.tile_h], "fma_policy": int(fma), "tiles": recs,
                         "oracle": "oracle/rayn_oracle.cpp, " + ("FUSED mul_add (librayn_oracle_fma.so)" if fma else "unfused mul_add (librayn_oracle.so)"),
                         "oracle_hash": oracle_hash(), "seconds": round(time.time() - t0, 1)}
+        if base_config(name) in EXTENSION_CONFIGS:
+            result[name]["note"] = EXTENSION_NOTE
         if base_config(name) == "c1":  # every tile of the frame is listed: whole-frame counts
             result[name]["frame_counts"] = {k: sum(r[k] for r in recs) for k in ("paths", "segments", "packets", "dist_evals")}
         json.dump(result, open(args.out, "w"), indent=1)

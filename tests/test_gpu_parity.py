@@ -484,6 +484,15 @@ def _custom_world(kind, res):
             k += 1
     elif kind == "lambert_sdf_sphere":
         world.hitables[1] = R.TracedSDF(R.SphereSDF(1.0), world.materials.add_material(R.Lambertian(R.Srgb(0.5, 0.5, 0.5))))
+    elif kind == "huge_lights":
+        # r6 (zero-throughput NEE elision, k_shade_setup): one light of absurd power and size next to an over-bright dielectric, volume on.  Close to that light
+        # pdf < 1 and x = Le * f * tr lies within a factor 1/pdf of FLT_MAX, so (x * occluded) / pdf is +inf for a VISIBLE sample and 0 for an occluded one;
+        # on a segment whose throughput is exactly 0 the reference then adds inf * 0 = NaN (src/integrator.rs:91-92) or nothing - the march outcome reaches
+        # the film, the sample fails the elision's bounds (|x| <= 2^60) and must be tested and marched like any other.
+        cam_h, world = S.setup(res, volumes=True, sdf="mandelbox")
+        world.lights[1].emission = R.Srgb(3.3e38, 1e38, 3e37)
+        world.lights[1].rad = 0.9
+        world.materials[1] = R.Dielectric.new_remap(R.Srgb(3.0, 3.0, 3.0), 0.6)
     else:
         raise ValueError(kind)
     return world.to_desc(cam_h)
@@ -505,6 +514,45 @@ def test_closed_set_parity(gpu_ctx, oracle, kind):
     assert film_l2(out, ref) < L2_TOL
     assert film_equal_bits(out, ref)
     assert np.abs(ref["color"]).sum() + np.abs(ref["background"]).sum() > 0
+
+
+def test_zero_throughput_elision_counts_and_fallback(gpu_ctx, oracle):
+    """r6: k_shade_setup parks no shadow segment for a NEE sample whose weight is an exact zero (throughput (0, 0, 0), DielectricBSDF::scatter's zeroed
+    specular lobe, src/material.rs:240-243; every NEE term is multiplied by it, src/integrator.rs:91-92,128-129).  (1) On the shipped scene the elision is
+    active (counted by the instrumented kernels), never needs its fallback, and the film keeps every bit.  (2) "huge_lights" forces the fallback: samples
+    whose contribution is not provably finite are marched as ever, because inf * 0 = NaN must reach the film exactly where the reference produces it."""
+    from rayn_amd import params as P
+    wd, p = case("s2", 40, 24, 4, 8)
+    tabs = _tables(oracle, p)
+    ref, ctr = oracle.render(wd, p, tabs)
+    gpu_ctx.upload_world(wd)
+    gpu_ctx.set_profiling(False, True)
+    try:
+        out = gpu_ctx.render_host(p, tabs)
+        el, st = gpu_ctx.elision_counts(), gpu_ctx.stats()
+        assert film_equal_bits(out, ref) and st["segments"] == ctr.segments
+        assert 0 < el["zero_throughput_slots"] < st["segments"] and el["elided_shadow_jobs"] > 0 and el["samples_out_of_bounds"] == 0, el
+        gpu_ctx.set_profiling(False, False)
+        jobs_counted = st["shadow_jobs"]
+        out = gpu_ctx.render_host(p, tabs)  # the product kernels: same film, same job count as the instrumented ones
+        assert film_equal_bits(out, ref) and gpu_ctx.stats()["shadow_jobs"] == jobs_counted
+        w, h = 48, 32
+        wd = _custom_world("huge_lights", (w, h))
+        p = P.frame_params(w, h, 4, 6)
+        tabs = _tables(oracle, p)
+        ref, ctr = oracle.render(wd, p, tabs)
+        nan_px = int(np.isnan(ref["color"]).any(-1).sum())
+        assert nan_px > 0 and np.isfinite(ref["color"]).all(-1).sum() > 100 and np.isinf(ref["color"]).any(-1).sum() > nan_px
+        gpu_ctx.upload_world(wd)
+        gpu_ctx.set_profiling(False, True)
+        out = gpu_ctx.render_host(p, tabs)
+        el, st = gpu_ctx.elision_counts(), gpu_ctx.stats()
+        assert st["segments"] == ctr.segments
+        assert film_equal_bits(out, ref)  # NaNs compare equal whatever their payload (common.bits_equal), everything else bit for bit
+        assert np.array_equal(np.isnan(out["color"]), np.isnan(ref["color"]))
+        assert el["samples_out_of_bounds"] > 0 and el["zero_throughput_slots"] > 0, el
+    finally:
+        gpu_ctx.set_profiling(False, False)
 
 
 def test_box_filter_tables_parity(gpu_ctx, oracle):

@@ -1,17 +1,18 @@
 #!/bin/bash
-# Register / scratch / LDS use of every kernel in a compiled object (code-object metadata notes): no GPU needed.
-# usage: bash tools/kernel_resources.sh [rayn_amd/csrc/kernels_p0.o]
-OBJ=${1:-rayn_amd/csrc/kernels_p0.o}
-TMP=$(mktemp -d)
-/opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$TMP/fb.bin $OBJ
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$TMP/fb.bin --output=$TMP/dev.co --unbundle
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $TMP/dev.co | python3 -c "
-import sys, re
-txt = sys.stdin.read()
-for blk in txt.split('- .agpr_count')[1:]:
-    g = lambda k: (re.search(r'\.%s:\s*(\S+)' % k, blk) or [None, '?'])[1]
-    name = g('name')
-    name = re.sub(r'^_ZN\d+rayn_p\d\d*', '', name)
-    print(f\"{name[:60]:60s} vgpr {g('vgpr_count'):>4s} sgpr {g('sgpr_count'):>4s} scratch {g('private_segment_fixed_size'):>5s} lds {g('group_segment_fixed_size'):>6s} spill_v {g('vgpr_spill_count'):>3s} spill_s {g('sgpr_spill_count'):>3s}\")
+# Register / scratch / occupancy figures of every kernel of rayn_amd/csrc/kernels.hip as the product flags compile it (policy 0).
+#   tools/kernel_resources.sh [kernels.hip] [extra hipcc flags]
+here=$(cd "$(dirname "$0")/.." && pwd)
+src=${1:-$here/rayn_amd/csrc/kernels.hip}; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -align-all-nofallthru-blocks=5 -fPIC \
+  -I"$here/rayn_amd/csrc" -DRAYN_FMA_POLICY=0 -DRAYN_KNS=rayn_p0 "$@" -Rpass-analysis=kernel-resource-usage -c -o /tmp/kernel_resources.o "$src" 2>&1 | python3 -c "
+import re, subprocess, sys
+cur = None; d = {}
+for l in sys.stdin:
+    m = re.search(r'Function Name: (\S+)', l)
+    if m: cur = m.group(1); d[cur] = {}; continue
+    m = re.search(r'remark:\s+(VGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)', l)
+    if m and cur: d[cur][m.group(1).split(' [')[0]] = int(m.group(2))
+for k, v in d.items():
+    name = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip()
+    print(re.sub(r'\(.*', '', name).replace('rayn_p0::', '').replace('void ', ''), v)
 "
-rm -rf $TMP
