@@ -339,6 +339,9 @@ def main():
         torch.cuda.synchronize()
         ev = ctx.eval_counts()
         it = ctx.sdf_iterations()
+        el = ctx.elision_counts()
+        slots = ctx.stage_slots()
+        st_count = ctx.stats()
         ctx.set_profiling(False, False)
         ctx.set_workers(2)
         # flop of the evaluations = per-iteration flop x the iterations the instrumented kernels COUNTED + the per-evaluation part (SDF_FLOPS):
@@ -373,7 +376,15 @@ def main():
                     "all_march_kernels": {k: {"ms": round(v[0], 3), "dist_evals": v[1], "flop_per_dist_eval": round(v[3] / v[1], 2) if v[1] else 0.0,
                                               "tflops": round(v[3] / max(v[0], 1e-9) / 1e9, 3)} for k, v in classes.items()},
                     "note": "march kernels are FP32-VALU bound (SURVEY.md F6): achieved = SDF-evaluation flop / kernel time; "
-                            "peak = MI355X FP32 vector peak (= dense f32-input MFMA peak)"}
+                            "peak = MI355X FP32 vector peak (= dense f32-input MFMA peak)",
+                    # r6, single-Mandelbulb scenes (march_bulb.h): occupancy of the two stages of an evaluation = lane slots used / lane slots offered (instrumented kernels)
+                    "bulb_stage_occupancy": None if not slots["shadow_orbit"] else {
+                        "k_shadow_bulb": {"orbit": round(it["shadow"] / max(slots["shadow_orbit"], 1), 4), "epilogue": round(ev["shadow"] / max(slots["shadow_epilogue"], 1), 4)}},
+                    # r6: shaded segments whose throughput is exactly (0, 0, 0) park no shadow segment (every NEE term is multiplied by that zero, src/integrator.rs:91-92,128-129;
+                    # exact - k_shade_setup): counted by the instrumented kernels; shadow_jobs_marched + elided_shadow_jobs = what r5 marched
+                    "zero_throughput_elision": {**el, "segments": st_count["segments"], "shadow_jobs_marched": st_count["shadow_jobs"],
+                                                "share_of_segments": round(el["zero_throughput_slots"] / max(st_count["segments"], 1), 4),
+                                                "share_of_shadow_jobs": round(el["elided_shadow_jobs"] / max(el["elided_shadow_jobs"] + st_count["shadow_jobs"], 1), 4)}}
         # HBM-bound queue kernels: algorithmic bytes / HIP-event time per kernel class
         npool = st["paths"]
         qk = {

@@ -296,6 +296,11 @@ int rayn_hip_get_sdf_iterations(const rayn_ctx* ctx, uint64_t out[3]);
  * kernel) - out[1] = the shadow segments those slots would have parked for TracedSDF::occluded (src/sdf.rs:25-57), out[2] = NEE samples of such
  * slots that were NOT elided because their contribution is not provably finite (then inf * 0 / NaN must keep its bits: tested and marched as ever) */
 int rayn_hip_get_elision_counts(const rayn_ctx* ctx, uint64_t out[3]);
+/* r6, same instrumented kernels, single-Mandelbulb scenes only (rayn_amd/csrc/march_bulb.h; zero otherwise): the shadow-march kernel written for that SDF runs an
+ * evaluation in two stages - orbit steps, then distance + one step of TracedSDF::occluded (src/sdf.rs:25-57) - each at its own occupancy.
+ * out[0] / out[1] = lane slots (64 x wave executions) the orbit / epilogue stage of k_shadow_bulb offered; the lane slots USED are
+ * rayn_hip_get_sdf_iterations()[2] (orbit steps) and rayn_hip_get_eval_counts()[2] (epilogues). */
+int rayn_hip_get_stage_slots(const rayn_ctx* ctx, uint64_t out[2]);
 /* A frame's tiles are dealt to up to two workers (host thread + HIP stream + own device memory each) so that one
  * worker's HBM-bound kernels and readbacks run underneath the other's VALU-bound marches.  n_workers 1..4 (default 2).
  * A further worker is only used while every worker still gets full-size batches and the call owns >= min_paths camera

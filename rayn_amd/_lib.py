@@ -35,7 +35,7 @@ EXPORTS = [
     "rayn_build_scramble", "rayn_build_fis_table", "rayn_build_fis_table_ex", "rayn_tile_count", "rayn_hip_set_profiling", "rayn_hip_get_eval_counts",
     "rayn_hip_set_batch_paths", "rayn_hip_set_cold_bytes", "rayn_hip_set_workers", "rayn_hip_set_tile_subset", "rayn_hip_set_trace_tile", "rayn_hip_get_trace", "rayn_hip_fma_policy", "rayn_hip_set_fma_policy", "rayn_hip_sizeof", "rayn_hip_probe_sdf_dist",
     "rayn_hip_probe_closest_hit", "rayn_hip_probe_occluded", "rayn_hip_probe_detmath", "rayn_hip_build_variant",
-    "rayn_hip_get_entry_stats", "rayn_hip_get_sdf_iterations", "rayn_hip_get_elision_counts", "rayn_share_pixels", "rayn_hip_render_frame_packed_device", "rayn_hip_unpack_share_device",
+    "rayn_hip_get_entry_stats", "rayn_hip_get_sdf_iterations", "rayn_hip_get_elision_counts", "rayn_hip_get_stage_slots", "rayn_share_pixels", "rayn_hip_render_frame_packed_device", "rayn_hip_unpack_share_device",
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.rayn_hip_get_eval_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rayn_hip_get_sdf_iterations.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rayn_hip_get_elision_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.rayn_hip_get_stage_slots.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rayn_hip_set_batch_paths.argtypes = [vp, C.c_uint64]
         L.rayn_hip_set_cold_bytes.argtypes = [vp, C.c_uint64]
         L.rayn_hip_set_workers.argtypes = [vp, C.c_int, C.c_uint64]

@@ -176,28 +176,37 @@ struct EvalCtr { uint32_t n = 0, it = 0; };
 // The logarithm is kept OUT of line: inlined, its twelve binary64 coefficients are hoisted into 24 scalar registers for the
 // whole march kernel, which then sits at the 102-SGPR ceiling and marches MandelBox scenes 4 % slower (k_shadow1, c3).
 __device__ __attribute__((noinline)) static float bulb_logf(float m) { return dm_logf(m); }
+// The estimator in three pieces - orbit state at the point, ONE orbit step, the distance from the final (|w|^2, dz) - so that the march kernels
+// written for this SDF (march_bulb.h: one loop trip = one orbit STEP) run exactly the operations of the whole-evaluation form below.
+struct BulbOrbit { f3 w; float m, dz; };
+RD BulbOrbit bulb_begin(f3 p) { return BulbOrbit{p, p.x * p.x + p.y * p.y + p.z * p.z, 1.0f}; }
+RD void bulb_step(BulbOrbit& o, f3 p) {
+    const f3 w = o.w;
+    const float m = o.m;
+    const float m2 = m * m, m4 = m2 * m2;
+    o.dz = 8.0f * sqrt_rn(m4 * m2 * m) * o.dz + 1.0f;
+    const float x = w.x, x2 = x * x, x4 = x2 * x2;
+    const float y = w.y, y2 = y * y, y4 = y2 * y2;
+    const float z = w.z, z2 = z * z, z4 = z2 * z2;
+    const float k3 = x2 + z2;
+    const float k2 = 1.0f / sqrt_rn(k3 * k3 * k3 * k3 * k3 * k3 * k3);
+    const float k1 = x4 + y4 + z4 - 6.0f * y2 * z2 - 6.0f * x2 * y2 + 2.0f * z2 * x2;
+    const float k4 = x2 - y2 + z2;
+    o.w.x = p.x + 64.0f * x * y * z * (x2 - z2) * k4 * (x4 - 6.0f * x2 * z2 + z4) * k1 * k2;
+    o.w.y = p.y + -16.0f * y2 * k3 * k4 * k4 + k1 * k1;
+    o.w.z = p.z + -8.0f * y * k4 * (x4 * x4 - 28.0f * x4 * x2 * z2 + 70.0f * x4 * z4 - 28.0f * x2 * z2 * z4 + z4 * z4) * k1 * k2;
+    o.m = o.w.x * o.w.x + o.w.y * o.w.y + o.w.z * o.w.z;
+}
+constexpr float BULB_BAILOUT = 256.0f;
+RD float bulb_finish(float m, float dz) { return 0.25f * bulb_logf(m) * sqrt_rn(m) / dz; }
 template <bool COUNT>
 RD float mandelbulb_dist(f3 p, uint32_t iterations, EvalCtr& evals) {
-    f3 w = p;
-    float m = w.x * w.x + w.y * w.y + w.z * w.z;
-    float dz = 1.0f;
+    BulbOrbit o = bulb_begin(p);
     for (uint32_t i = 0; i < iterations; i++) {
-        const float m2 = m * m, m4 = m2 * m2;
-        dz = 8.0f * sqrt_rn(m4 * m2 * m) * dz + 1.0f;
-        const float x = w.x, x2 = x * x, x4 = x2 * x2;
-        const float y = w.y, y2 = y * y, y4 = y2 * y2;
-        const float z = w.z, z2 = z * z, z4 = z2 * z2;
-        const float k3 = x2 + z2;
-        const float k2 = 1.0f / sqrt_rn(k3 * k3 * k3 * k3 * k3 * k3 * k3);
-        const float k1 = x4 + y4 + z4 - 6.0f * y2 * z2 - 6.0f * x2 * y2 + 2.0f * z2 * x2;
-        const float k4 = x2 - y2 + z2;
-        w.x = p.x + 64.0f * x * y * z * (x2 - z2) * k4 * (x4 - 6.0f * x2 * z2 + z4) * k1 * k2;
-        w.y = p.y + -16.0f * y2 * k3 * k4 * k4 + k1 * k1;
-        w.z = p.z + -8.0f * y * k4 * (x4 * x4 - 28.0f * x4 * x2 * z2 + 70.0f * x4 * z4 - 28.0f * x2 * z2 * z4 + z4 * z4) * k1 * k2;
-        m = w.x * w.x + w.y * w.y + w.z * w.z;
-        if (m > 256.0f) { if (COUNT) evals.it -= iterations - 1u - i; break; } // orbit steps NOT run (roofline accounting only)
+        bulb_step(o, p);
+        if (o.m > BULB_BAILOUT) { if (COUNT) evals.it -= iterations - 1u - i; break; } // orbit steps NOT run (roofline accounting only)
     }
-    return 0.25f * bulb_logf(m) * sqrt_rn(m) / dz;
+    return bulb_finish(o.m, o.dz);
 }
 
 // max(a, b) for non-NaN operands as a single instruction

@@ -86,6 +86,13 @@ struct Tuning {
     uint32_t prefetch_min_extend = 32;    // fast path: lanes without a spare ray before the bulk queue fetch
     uint32_t prefetch_min_shadow = 32;
     bool fast_path = true;                // single-SDF specialisations k_extend1 / k_shadow1
+    // march_bulb.h: the shadow-march kernel written for a single-Mandelbulb scene (K rays per lane, rounds of refill / orbits / epilogues)
+    bool bulb_path = true;                // use it when the scene's one SDF is a Mandelbulb ...
+    bool bulb = false;                    // ... which the host decides per frame (render_device); never set by a caller
+    uint32_t bulb_steps = 1;              // orbit steps per trip of the orbit phase (1 or 2)
+    uint32_t bulb_rays = 3;               // rays per lane of k_shadow_bulb (2, 3 or 4)
+    uint32_t bulb_orbit_min = 24;         // the orbit phase of a round ends when at most this many lanes are still inside an orbit
+    uint32_t bulb_prefetch_min = 32;      // free ray slots of a wave before the bulk queue fetch
 };
 
 // sample tables: the reference layout (src/sampler.rs:11-15) + a per-(depth, sample) packed copy built at

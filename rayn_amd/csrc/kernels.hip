@@ -742,7 +742,8 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
     // end a path before depth 3 (src/integrator.rs:147-156), so 9 % of the shaded segments of config 3 (24 % at depth 2, 33 % at depth 3;
     // zero is absorbing: 0 * f stays 0, a NaN product keeps the old throughput, src/integrator.rs:181) arrive with throughput 0.  Every NEE
     // term of such a segment is   rad + ((x * occluded) / pdf) * thr * corr * (vol_T | rho_s * aux)   (src/integrator.rs:91-92,128-129):
-    // with |x| <= 2^60 and pdf >= 2^-60 (or +inf) the quotient is FINITE for occluded = 0 and for 1, finite * (+-0) is +-0, it stays +-0
+    // with |x| <= 2^60 and |pdf| >= 2^-60 (infinite too; negative too: a march that ends inside the Mandelbulb returns a negative hit distance and with it
+    // a negative equi-angular pdf - 15 % of the zero-throughput samples of bulb3) the quotient is FINITE for occluded = 0 and for 1, finite * (+-0) is +-0, it stays +-0
     // through the finite factors that follow, and rad + (+-0) == rad bit for bit (rad is never -0: it starts at +0 and a sum is -0 only
     // when both terms are).  The visibility of such a sample cannot reach the film: no sphere tests, no parked segment, no shadow march
     // (vis stays 1; k_shade_finish adds its exact zero).  The path itself goes on: its hit object still decides packet membership
@@ -780,7 +781,7 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
                 nee.pdf[i * cap + j] = pdf;
                 uint8_t vis = 1;
                 // x == 0 (light below the horizon): (x*occluded)/pdf is the same zero for occluded 0 or 1 -> no test needed
-                const bool zw = zero_w && __builtin_fabsf(x.x) <= ELIDE_MAX_X && __builtin_fabsf(x.y) <= ELIDE_MAX_X && __builtin_fabsf(x.z) <= ELIDE_MAX_X && pdf >= ELIDE_MIN_PDF;
+                const bool zw = zero_w && __builtin_fabsf(x.x) <= ELIDE_MAX_X && __builtin_fabsf(x.y) <= ELIDE_MAX_X && __builtin_fabsf(x.z) <= ELIDE_MAX_X && __builtin_fabsf(pdf) >= ELIDE_MIN_PDF;
                 if (COUNT) { if (zw && !all_zero(x) && scene_has_sdf && spheres_visible(occlude_point, end_point)) n_elided_jobs++; if (zero_w && !zw) n_oob++; }
                 if (!all_zero(x) && !zw) {
                     if (!spheres_visible(occlude_point, end_point)) vis = 0;
@@ -842,7 +843,7 @@ __global__ void __launch_bounds__(256, SETUP_WAVES) k_shade_setup(const DScene* 
                     uint8_t vis = 1;
                     // zero-weight slot (see above): x = Le * (1/(4 pi) * tr) with the constant factor <= 1 and tr the only variable, pdf = vpdf * lpdf, then * rho_s * aux
                     const bool zw = zero_w && __builtin_fabsf(L.emission.x * tr) <= ELIDE_MAX_X && __builtin_fabsf(L.emission.y * tr) <= ELIDE_MAX_X &&
-                                    __builtin_fabsf(L.emission.z * tr) <= ELIDE_MAX_X && vpdf * lpdf >= ELIDE_MIN_PDF && __builtin_fabsf(vaux) <= FINITE_MAX;
+                                    __builtin_fabsf(L.emission.z * tr) <= ELIDE_MAX_X && __builtin_fabsf(vpdf * lpdf) >= ELIDE_MIN_PDF && __builtin_fabsf(vaux) <= FINITE_MAX;
                     if (COUNT) { if (zw && scene_has_sdf && spheres_visible(sp, end_point)) n_elided_jobs++; if (zero_w && !zw) n_oob++; }
                     if (zw) {}
                     else if (!spheres_visible(sp, end_point)) vis = 0;
@@ -1133,6 +1134,8 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     }
     if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
 }
+
+#include "march_bulb.h"
 
 __global__ void __launch_bounds__(256) k_shade_finish(const DScene* __restrict__ scp, const uint32_t* __restrict__ bq, const DCtl* __restrict__ ctl,
                                                        Pool pool, Nee nee) {
@@ -1883,7 +1886,7 @@ void launch_raygen(hipStream_t s, const DScene* sc, Tables tab, const float* scr
 void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, const uint32_t* q, uint32_t max_entries, Pool pool,
                    uint8_t* ent_obj, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun) {
     const dim3 grid = stride_grid(max_entries, 256, tun.persistent_blocks);
-    if (single_sdf >= 0 && tun.fast_path) {
+    if (single_sdf >= 0 && tun.fast_path) { // (a single-Mandelbulb scene keeps k_extend1 for its closest-hit marches: the k_shadow_bulb scheme measured slower here, tools/variants/r6_k_extend_bulb.h)
         if (count) hipLaunchKernelGGL(k_extend1<true>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
         else hipLaunchKernelGGL(k_extend1<false>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
     } else if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
@@ -1922,7 +1925,14 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
         hooks.before(1);
         hipLaunchKernelGGL(k_shadow_list, stride_grid(ns * max_slots, 256 * SCAN_ITEMS, STREAM_BLOCKS), dim3(256), 0, s, nee, ns, ctl);
         const dim3 grid = stride_grid(ns * max_slots, 256, tun.persistent_blocks);
-        if (single_sdf >= 0 && tun.fast_path) {
+        if (single_sdf >= 0 && tun.fast_path && tun.bulb) {
+#define RAYN_SHADOW_BULB(C, KK, SS) hipLaunchKernelGGL((k_shadow_bulb<C, KK, SS>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.bulb_orbit_min, tun.bulb_prefetch_min, evals + 2)
+            if (count) { if (tun.bulb_rays == 2) RAYN_SHADOW_BULB(true, 2, 1); else if (tun.bulb_rays == 3) RAYN_SHADOW_BULB(true, 3, 1); else RAYN_SHADOW_BULB(true, 4, 1); }
+            else if (tun.bulb_rays == 2) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 2, 2); else RAYN_SHADOW_BULB(false, 2, 1); }
+            else if (tun.bulb_rays == 3) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 3, 2); else RAYN_SHADOW_BULB(false, 3, 1); }
+            else { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 4, 2); else RAYN_SHADOW_BULB(false, 4, 1); }
+#undef RAYN_SHADOW_BULB
+        } else if (single_sdf >= 0 && tun.fast_path) {
             if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
             else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
         } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);

@@ -58,7 +58,7 @@ struct Worker {
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
     rayn_stats stats;
-    unsigned long long evals[3] = {0, 0, 0}, iters[3] = {0, 0, 0}, elided[3] = {0, 0, 0};
+    unsigned long long evals[3] = {0, 0, 0}, iters[3] = {0, 0, 0}, elided[3] = {0, 0, 0}, stage_slots[2] = {0, 0};
     std::string err;
     int rc = 0;
 };
@@ -78,6 +78,7 @@ struct rayn_ctx {
     rayn_stats stats;
     unsigned long long evals[3] = {0, 0, 0}; // extend, shade_setup (normals), shadow
     unsigned long long iters[3] = {0, 0, 0}; // fold / orbit iterations of those evaluations (instrumented kernels only)
+    unsigned long long stage_slots[2] = {0, 0}; // march_bulb.h, instrumented kernel: lane slots offered by the orbit / epilogue stage of k_shadow_bulb
     unsigned long long elided[3] = {0, 0, 0}; // zero-throughput slots, shadow segments they would have parked, their samples that took the ordinary path (instrumented kernels only)
     bool profiling = false, counting = false;
     size_t batch_paths = (size_t)1 << 28;   // per worker; also limited by the HBM budget and the 32-bit job refs (render_device)
@@ -306,6 +307,7 @@ struct FrameShared { // read-only for the workers
     float *d_color, *d_alpha, *d_bg, *d_normal;
     KernelSet K; int single_sdf; uint32_t NS; bool count, profiling;
     size_t batch_paths; // effective per-worker pool capacity of this frame
+    Tuning tun;         // the context's launch tuning + what this frame's scene decides (Tuning::bulb)
 };
 
 // everything one worker does for its share of the tiles: batches -> per-depth wavefront -> resolve
@@ -315,6 +317,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
     w->evals[0] = w->evals[1] = w->evals[2] = 0;
     w->iters[0] = w->iters[1] = w->iters[2] = 0;
     w->elided[0] = w->elided[1] = w->elided[2] = 0;
+    w->stage_slots[0] = w->stage_slots[1] = 0;
     if (mine.empty()) return 0;
     WCHK(hipSetDevice(ctx->device));
     const DScene& hs = F.hs;
@@ -461,7 +464,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
                 WCHK(hipStreamSynchronize(stream));
                 if (w->h_totals[1] == 0) break;
             }
-            { Timed t(w, prof, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, max_entries, pool, ent_obj, F.single_sdf, d_ctl, w->d_evals, ctx->tun); }
+            { Timed t(w, prof, PC_EXTEND); K.extend(stream, count, ctx->d_scene, depth, qcur, max_entries, pool, ent_obj, F.single_sdf, d_ctl, w->d_evals, F.tun); }
             w->stats.launches_extend++;
             {
                 Timed t(w, prof, PC_BIN);
@@ -506,7 +509,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
                 hooks.user = &hst;
                 hooks.before_fn = [](void* u, int i) { HookState* h = (HookState*)u; h->cur = new Timed(h->w, h->on, cls[i]); };
                 hooks.after_fn = [](void* u, int) { HookState* h = (HookState*)u; delete h->cur; h->cur = nullptr; };
-                K.shade(stream, count, ctx->d_scene, tab, F.d_scr, depth, bq, max_slots, pool, nee, NS, hs.n_sdf > 0, F.single_sdf, alive, bgrp_cnt, d_ctl, w->d_evals, hooks, ctx->tun);
+                K.shade(stream, count, ctx->d_scene, tab, F.d_scr, depth, bq, max_slots, pool, nee, NS, hs.n_sdf > 0, F.single_sdf, alive, bgrp_cnt, d_ctl, w->d_evals, hooks, F.tun);
             }
             w->stats.launches_shade++;
             if (depth == last_depth) break; // nothing survives the last depth: no repack
@@ -538,6 +541,7 @@ int run_worker(rayn_ctx* ctx, Worker* w, const FrameShared& F, const std::vector
         WCHK(hipMemcpy(h, w->d_evals, 128, hipMemcpyDeviceToHost));
         for (int k = 0; k < 3; k++) { w->evals[k] = h[k]; w->iters[k] = h[4 + k]; }
         w->elided[0] = h[3]; w->elided[1] = h[7]; w->elided[2] = h[8];
+        w->stage_slots[0] = h[12]; w->stage_slots[1] = h[13];
     }
     return 0;
 }
@@ -579,6 +583,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     ctx->evals[0] = ctx->evals[1] = ctx->evals[2] = 0;
     ctx->iters[0] = ctx->iters[1] = ctx->iters[2] = 0;
     ctx->elided[0] = ctx->elided[1] = ctx->elided[2] = 0;
+    ctx->stage_slots[0] = ctx->stage_slots[1] = 0;
     ctx->trace.clear();
     if (owned.empty()) return RAYN_OK;
 
@@ -596,6 +601,10 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     F.K = kernel_set(ctx->fma_policy);
     F.single_sdf = -1; // index of the TracedSDF when the scene holds exactly one (fast-path kernels)
     if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) F.single_sdf = (int)i;
+    F.tun = ctx->tun;
+    // a scene whose ONE TracedSDF is a Mandelbulb marches its shadow segments with the kernel written for it (march_bulb.h; the march count shares a register with two flags there)
+    F.tun.bulb = ctx->tun.bulb_path && F.single_sdf >= 0 && hs.h[F.single_sdf].sdf_kind == RAYN_SDF_MANDELBULB && hs.h[F.single_sdf].iterations >= 1 &&
+                 p->max_marches < 0xFFFFu && p->max_vis_marches < 0xFFFFu;
     F.tab = Tables{d_s1, d_s2, d_fis, ctx->d_rec, rec_stride};
     F.K.pack_tables(stream, F.tab, ctx->d_rec, spp, rec_depths, hs.n1, hs.n2);
     F.d_scr = d_scr; F.d_color = d_color; F.d_alpha = d_alpha; F.d_bg = d_bg; F.d_normal = d_normal;
@@ -674,6 +683,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
         ctx->stats.shadow_jobs += w.stats.shadow_jobs;
         for (int k = 0; k < 3; k++) { ctx->evals[k] += w.evals[k]; ctx->iters[k] += w.iters[k]; }
         for (int k = 0; k < 3; k++) ctx->elided[k] += w.elided[k];
+        for (int k = 0; k < 2; k++) ctx->stage_slots[k] += w.stage_slots[k];
     }
     HIPCHK(hipEventRecord(ctx->ev_b, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -830,6 +840,7 @@ int render_multi(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, c
         total.ms_resolve += s.ms_resolve; total.ms_shadow += s.ms_shadow; total.ms_finish += s.ms_finish;
         for (int k = 0; k < 3; k++) { ctx->evals[k] += c->evals[k]; ctx->iters[k] += c->iters[k]; }
         for (int k = 0; k < 3; k++) ctx->elided[k] += c->elided[k];
+        for (int k = 0; k < 2; k++) ctx->stage_slots[k] += c->stage_slots[k];
     }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev_ma, ctx->ev_mb);
@@ -888,6 +899,11 @@ int rayn_hip_create(int device, rayn_ctx** out) {
         if (const char* e = getenv("RAYN_HIP_PREFETCH_SHADOW")) ctx->tun.prefetch_min_shadow = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("RAYN_HIP_FAST_PATH")) ctx->tun.fast_path = atoi(e) != 0;
         if (const char* e = getenv("RAYN_HIP_PERSISTENT_BLOCKS")) ctx->tun.persistent_blocks = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = getenv("RAYN_HIP_BULB_PATH")) ctx->tun.bulb_path = atoi(e) != 0;
+        if (const char* e = getenv("RAYN_HIP_BULB_STEPS")) ctx->tun.bulb_steps = atoi(e) == 2 ? 2u : 1u;
+        if (const char* e = getenv("RAYN_HIP_BULB_ORBIT_MIN")) ctx->tun.bulb_orbit_min = (uint32_t)std::max(0, atoi(e));
+        if (const char* e = getenv("RAYN_HIP_BULB_RAYS")) ctx->tun.bulb_rays = (uint32_t)std::min(4, std::max(2, atoi(e)));
+        if (const char* e = getenv("RAYN_HIP_BULB_PREFETCH")) ctx->tun.bulb_prefetch_min = (uint32_t)std::max(1, atoi(e));
     }
     *out = ctx;
     return RAYN_OK;
@@ -1134,6 +1150,11 @@ int rayn_hip_get_sdf_iterations(const rayn_ctx* ctx, uint64_t out[3]) {
 int rayn_hip_get_elision_counts(const rayn_ctx* ctx, uint64_t out[3]) {
     if (!ctx || !out) return RAYN_ERR_INVALID_ARG;
     for (int k = 0; k < 3; k++) out[k] = ctx->elided[k];
+    return RAYN_OK;
+}
+int rayn_hip_get_stage_slots(const rayn_ctx* ctx, uint64_t out[2]) {
+    if (!ctx || !out) return RAYN_ERR_INVALID_ARG;
+    for (int k = 0; k < 2; k++) out[k] = ctx->stage_slots[k];
     return RAYN_OK;
 }
 int rayn_hip_set_batch_paths(rayn_ctx* ctx, uint64_t paths) {

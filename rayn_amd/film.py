@@ -142,6 +142,12 @@ class Context:
         self._chk(self._L.rayn_hip_get_elision_counts(self.h, out))
         return {"zero_throughput_slots": out[0], "elided_shadow_jobs": out[1], "samples_out_of_bounds": out[2]}
 
+    def stage_slots(self):
+        """Instrumented Mandelbulb shadow-march kernel (rayn_hip_get_stage_slots): lane slots offered by the orbit / epilogue stage of k_shadow_bulb."""
+        out = (C.c_uint64 * 2)()
+        self._chk(self._L.rayn_hip_get_stage_slots(self.h, out))
+        return {"shadow_orbit": out[0], "shadow_epilogue": out[1]}
+
     def render_host(self, params, tables, out=None):
         """rayn_hip_render_frame with host (numpy) buffers.  Returns the film dict."""
         s1, s2, scr, fis = tables

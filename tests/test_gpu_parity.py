@@ -348,6 +348,49 @@ def test_tuning_variants_are_invisible(oracle, monkeypatch):
         assert film_equal_bits(out, ref), env
 
 
+def test_bulb_march_kernel_variants_are_invisible(oracle, monkeypatch):
+    """r6: a single-Mandelbulb scene marches its shadow segments with k_shadow_bulb (rayn_amd/csrc/march_bulb.h: K rays per lane, rounds of refill / orbits /
+    epilogues, orbits pulled from a per-wave job list in LDS and carried across rounds).  Every shape of it - 2 / 3 / 4 rays per lane, one or two orbit steps
+    per trip, drain-everything rounds (ORBIT_MIN 0), eager and lazy refill - and the generic k_shadow1 give the oracle's film bit for bit, with and without the
+    volume, with a moving bulb (packet times) and with exhausted march budgets."""
+    import rayn_amd
+    from rayn_amd import params as P
+    cases = []
+    for name, kw in (("bulbv", {}), ("bulb", {"max_marches": 12, "max_vis_marches": 5}), ("bulbm", {})):
+        cam, world = rayn_amd.setup.SCENES[name]((40, 24))
+        wd = world.to_desc(cam)
+        p = P.frame_params(40, 24, 2, 4, **kw)
+        tabs = _tables(oracle, p)
+        cases.append((wd, p, tabs, oracle.render(wd, p, tabs)))
+    monkeypatch.setenv("RAYN_HIP_ENV_TUNING", "1")
+    envs = ({"RAYN_HIP_BULB_PATH": "0"}, {}, {"RAYN_HIP_BULB_RAYS": "2", "RAYN_HIP_BULB_STEPS": "2"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_ORBIT_MIN": "0"},
+            {"RAYN_HIP_BULB_RAYS": "3", "RAYN_HIP_BULB_ORBIT_MIN": "63", "RAYN_HIP_BULB_PREFETCH": "1"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_STEPS": "2", "RAYN_HIP_BULB_PREFETCH": "200"})
+    for env in envs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = rayn_amd.Context(0)
+        try:
+            for wd, p, tabs, (ref, ctr) in cases:
+                ctx.upload_world(wd)
+                out = ctx.render_host(p, tabs)
+                st = ctx.stats()
+                assert st["segments"] == ctr.segments and st["shadow_jobs"] > 0
+                assert film_equal_bits(out, ref), env
+            if not env:  # the instrumented variant of the shipped shape: same film, and the stage accounting bench.py quotes is consistent
+                wd, p, tabs, (ref, ctr) = cases[0]
+                ctx.upload_world(wd)
+                ctx.set_profiling(False, True)
+                out = ctx.render_host(p, tabs)
+                ev, it, slots = ctx.eval_counts(), ctx.sdf_iterations(), ctx.stage_slots()
+                ctx.set_profiling(False, False)
+                assert film_equal_bits(out, ref)
+                assert 0 < it["shadow"] <= slots["shadow_orbit"] and 0 < ev["shadow"] <= slots["shadow_epilogue"], (ev, it, slots)
+        finally:
+            ctx.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_env_tuning_is_opt_in(oracle, monkeypatch):
     """A host that merely exports RAYN_HIP_BATCH_PATHS / RAYN_HIP_PROFILE does not change how its frames run: the library reads its
     tuning variables only when RAYN_HIP_ENV_TUNING=1 is set at context creation (include/rayn_hip.h)."""
