@@ -349,22 +349,26 @@ int rayn_hip_set_tile_subset(rayn_ctx* ctx, const uint32_t* tiles, uint32_t n);
 int rayn_hip_set_trace_tile(rayn_ctx* ctx, int tile_index);
 int64_t rayn_hip_get_trace(const rayn_ctx* ctx, uint32_t* out, uint64_t cap_records);
 
-/* ---- test probes: device per-lane primitives on caller data (HOST pointers).  They exist so the
- * parity tests can compare single functions with the CPU oracle lane for lane:
- *   SDF::dist (src/sdf.rs:125-140), HitableStore::add_hits' closest hit (src/hitable.rs:177-198;
- *   out_obj 0xFFFFFFFF = none), HitableStore::test_occluded (src/hitable.rs:164-168), and the pinned
- *   elementary functions (op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b)).
+/* ---- test probes on caller data (HOST pointers), so that the parity tests can compare single functions with the CPU oracle lane for lane:
+ *   rayn_hip_probe_sdf_dist   SDF::dist (src/sdf.rs:125-140) of one TracedSDF, a per-lane device function;
+ *   rayn_hip_probe_extend     HitableStore::add_hits' closest hit (src/hitable.rs:177-198 over Sphere::hit and TracedSDF::hit, src/sdf.rs:59-83) through the
+ *                             PRODUCT extend kernel of the uploaded scene (k_extend1, or the generic k_extend of a multi-SDF scene) on a synthetic ray queue of
+ *                             the n rays, ray time 0; out_obj 0xFFFFFFFF = none;
+ *   rayn_hip_probe_shadow     the TracedSDF::occluded factors of HitableStore::test_occluded (src/hitable.rs:164-168, src/sdf.rs:25-57; the analytic spheres are
+ *                             resolved by the shading kernel) through the PRODUCT shadow-march kernel (k_shadow1, k_shadow_bulb, the generic k_shadow) on a
+ *                             synthetic job list of the n segments: 1.0 visible, 0.0 occluded;
+ *   rayn_hip_probe_detmath    the pinned elementary functions (op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b)).
  *   Ops 6.. check the kernels' exact replacements of IEEE '/' and sqrt against the hardware IEEE
  *   result: 6 Newton-Raphson a/b, 7 IEEE a/b, 8 sqrt(a), 9/10/11 component x/y/z of v/|v| and
  *   12 |v| (a holds n xyz triples), 13 exhaustive sqrt sweep (out[i] = mismatch count over the
  *   65536 float bit patterns starting at bits(a[i])). */
 int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t hitable_index,
                             const float* pts_xyz, float* out, uint32_t n);
-int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth,
-                               const float* org_xyz, const float* dir_xyz, float* out_t,
-                               uint32_t* out_obj, uint32_t n);
-int rayn_hip_probe_occluded(rayn_ctx* ctx, const rayn_frame_params* p, const float* start_xyz,
-                            const float* end_xyz, float* out, uint32_t n);
+int rayn_hip_probe_extend(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth,
+                          const float* org_xyz, const float* dir_xyz, float* out_t,
+                          uint32_t* out_obj, uint32_t n);
+int rayn_hip_probe_shadow(rayn_ctx* ctx, const rayn_frame_params* p, const float* start_xyz,
+                          const float* end_xyz, float* out, uint32_t n);
 int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const float* b, float* out,
                            uint32_t n);
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "rayn_hip_render_frame_device", "rayn_hip_get_stats", "rayn_sets_1d", "rayn_sets_2d", "rayn_build_rd_tables",
     "rayn_build_scramble", "rayn_build_fis_table", "rayn_build_fis_table_ex", "rayn_tile_count", "rayn_hip_set_profiling", "rayn_hip_get_eval_counts",
     "rayn_hip_set_batch_paths", "rayn_hip_set_cold_bytes", "rayn_hip_set_workers", "rayn_hip_set_tile_subset", "rayn_hip_set_trace_tile", "rayn_hip_get_trace", "rayn_hip_fma_policy", "rayn_hip_set_fma_policy", "rayn_hip_sizeof", "rayn_hip_probe_sdf_dist",
-    "rayn_hip_probe_closest_hit", "rayn_hip_probe_occluded", "rayn_hip_probe_detmath", "rayn_hip_build_variant",
+    "rayn_hip_probe_extend", "rayn_hip_probe_shadow", "rayn_hip_probe_detmath", "rayn_hip_build_variant",
     "rayn_hip_get_entry_stats", "rayn_hip_get_sdf_iterations", "rayn_hip_get_elision_counts", "rayn_hip_get_stage_slots", "rayn_share_pixels", "rayn_hip_render_frame_packed_device", "rayn_hip_unpack_share_device",
 ]
 
@@ -107,8 +107,8 @@ def lib():
         L.rayn_hip_sizeof.restype = C.c_size_t
         L.rayn_hip_sizeof.argtypes = [C.c_int]
         L.rayn_hip_probe_sdf_dist.argtypes = [vp, C.POINTER(_abi.FrameParams), C.c_uint32, fp, fp, C.c_uint32]
-        L.rayn_hip_probe_closest_hit.argtypes = [vp, C.POINTER(_abi.FrameParams), C.c_uint32, fp, fp, fp, up, C.c_uint32]
-        L.rayn_hip_probe_occluded.argtypes = [vp, C.POINTER(_abi.FrameParams), fp, fp, fp, C.c_uint32]
+        L.rayn_hip_probe_extend.argtypes = [vp, C.POINTER(_abi.FrameParams), C.c_uint32, fp, fp, fp, up, C.c_uint32]
+        L.rayn_hip_probe_shadow.argtypes = [vp, C.POINTER(_abi.FrameParams), fp, fp, fp, C.c_uint32]
         L.rayn_hip_probe_detmath.argtypes = [vp, C.c_uint32, fp, fp, fp, C.c_uint32]
         L.rayn_hip_build_variant.restype = C.c_char_p
         L.rayn_hip_build_variant.argtypes = []

@@ -337,48 +337,6 @@ RD float thr_at(const Thr& th, float t) { return th.constant ? th.k : th.k * t; 
 // only case the reference has, is an exact no-op (x - 0 == x).
 RD f3 sphere_center(const DHitable& h, float t0) { return h.animated ? h.center + h.center_vel * t0 : h.center; }
 
-// TracedSDF::hit, src/sdf.rs:59-83 (per lane; a stopped lane is idempotent in the packet loop)
-template <bool COUNT>
-RD float sdf_hit(const DScene& sc, const DHitable& h, f3 o, f3 d, float t_max, const Thr& th, float t0, EvalCtr& evals) {
-    o = o - sphere_center(h, t0);
-    const float sv = sdf_scale(h, t0);
-    float t = sdf_dist<COUNT>(h, o, evals, sv);
-    const bool nan = t != t;
-    const float c0 = 0.00005f * sc.detail_scale, c1 = 0.05f * sc.detail_scale;
-    for (uint32_t m = 0; m < sc.max_marches; m++) {
-        f3 p = muladd3(d, t, o);
-        float dist = sdf_dist<COUNT>(h, p, evals, sv);
-        bool hit = __builtin_fabsf(dist) < fmaxs(c0, c1 * thr_at(th, t));
-        bool gt = t > t_max;
-        if (hit || nan || gt) break;
-        t = t + dist;
-    }
-    return t;
-}
-// TracedSDF::occluded, src/sdf.rs:25-57 (returns 1 = visible, 0 = occluded)
-template <bool COUNT>
-RD float sdf_occluded(const DScene& sc, const DHitable& h, f3 start, f3 end, float t0, EvalCtr& evals) {
-    const f3 origin = sphere_center(h, t0);
-    start = start - origin;
-    end = end - origin;
-    f3 dir = end - start;
-    float max_dist = mag(dir);
-    dir = div_by_mag(dir, max_dist);
-    const float sv = sdf_scale(h, t0);
-    float dist0 = sdf_dist<COUNT>(h, start, evals, sv);
-    const bool nan = dist0 != dist0;
-    if (sc.max_vis_marches == 0) return ((dist0 < 0.0001f) && !((dist0 > max_dist) || nan)) ? 0.0f : 1.0f;
-    const float c0 = 0.0001f * sc.detail_scale, c1 = 0.00001f * sc.detail_scale;
-    float t = dist0;
-    for (uint32_t m = 0; m < sc.max_vis_marches; m++) {
-        if ((t > max_dist) || nan) return 1.0f;
-        f3 p = muladd3(dir, t, start);
-        float dist = sdf_dist<COUNT>(h, p, evals, sv);
-        if (__builtin_fabsf(dist) < fmaxs(c0, c1 * t)) return 0.0f;
-        t = t + dist;
-    }
-    return 1.0f;
-}
 // sdfu normals_fast (tetrahedron), called at src/sdf.rs:94-96
 template <bool COUNT>
 RD f3 sdf_normal(const DHitable& h, f3 p, float eps, EvalCtr& evals, float sv) {
@@ -431,36 +389,6 @@ RD float sphere_occluded_dir(const DHitable& h, f3 start, f3 dir, float dist, fl
     float mn = fmins(t1, t2);
     bool valid = (mn > 0.001f) && (t1 <= dist) && desc_pos;
     return valid ? 0.0f : 1.0f;
-}
-RD float sphere_occluded(const DHitable& h, f3 start, f3 end, float t0) {
-    f3 dir = end - start;
-    float dist = mag(dir);
-    dir = div_by_mag(dir, dist);
-    return sphere_occluded_dir(h, start, dir, dist, t0);
-}
-
-// HitableStore::add_hits fold, src/hitable.rs:177-198: closest-so-far is the next t_max.
-template <bool COUNT>
-RD void closest_hit(const DScene& sc, f3 o, f3 d, const Thr& th, float t0, float* out_t, uint32_t* out_obj, EvalCtr& evals) {
-    float closest = sc.t_max;
-    uint32_t id = OBJ_NONE;
-    for (uint32_t k = 0; k < sc.n_hitables; k++) {
-        const DHitable& h = sc.h[k];
-        float t = h.kind == RAYN_HITABLE_SPHERE ? sphere_hit(h, o, d, closest, t0) : sdf_hit<COUNT>(sc, h, o, d, closest, th, t0, evals);
-        if (t < closest) { closest = t; id = k; }
-    }
-    *out_t = closest;
-    *out_obj = id;
-}
-// HitableStore::test_occluded, src/hitable.rs:164-168.  Every factor is exactly 0 or 1, so the
-// product is order-independent: analytic spheres first, SDF marches only if still visible.
-template <bool COUNT>
-RD float test_occluded(const DScene& sc, f3 start, f3 end, float t0, EvalCtr& evals) {
-    for (uint32_t k = 0; k < sc.n_hitables; k++)
-        if (sc.h[k].kind == RAYN_HITABLE_SPHERE && sphere_occluded(sc.h[k], start, end, t0) == 0.0f) return 0.0f;
-    for (uint32_t k = 0; k < sc.n_hitables; k++)
-        if (sc.h[k].kind != RAYN_HITABLE_SPHERE && sdf_occluded<COUNT>(sc, sc.h[k], start, end, t0, evals) == 0.0f) return 0.0f;
-    return 1.0f;
 }
 
 // ---- SphereLight (src/light.rs:38-107) ---------------------------------------------------------------

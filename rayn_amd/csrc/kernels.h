@@ -137,8 +137,7 @@ struct Tables {
     void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_t n_tiles, uint32_t max_tile_pixels, uint32_t spp, Pool pool, \
                         float* out_color, float* out_alpha, float* out_background, float* out_normal, const uint32_t* base_hist, uint32_t hist_stride); \
     void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n); \
-    void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n); \
-    void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n); \
+    void launch_shadow_march(hipStream_t s, bool count, const DScene* sc, Nee nee, uint32_t max_jobs, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun); \
     void launch_probe_detmath(hipStream_t s, uint32_t op, const float* a, const float* b, float* out, uint32_t n); \
     void launch_verify_short_div(hipStream_t s, float n, uint32_t lo_bits, uint32_t count, uint32_t* bad); \
     }
@@ -159,11 +158,10 @@ struct KernelSet {
     decltype(&rayn_p0::launch_batch_setup) batch_setup;
     decltype(&rayn_p0::launch_resolve) resolve;
     decltype(&rayn_p0::launch_probe_dist) probe_dist;
-    decltype(&rayn_p0::launch_probe_closest) probe_closest;
-    decltype(&rayn_p0::launch_probe_occluded) probe_occluded;
+    decltype(&rayn_p0::launch_shadow_march) shadow_march;
     decltype(&rayn_p0::launch_probe_detmath) probe_detmath;
 };
-#define RAYN_KERNEL_SET(NS) KernelSet{&NS::launch_pack_tables, &NS::launch_raygen, &NS::launch_extend, &NS::launch_group_hist, &NS::launch_scan_tile, &NS::launch_tile_prefix, &NS::launch_bin_scatter, &NS::launch_shade, &NS::launch_compact_scatter, &NS::launch_batch_setup, &NS::launch_resolve, &NS::launch_probe_dist, &NS::launch_probe_closest, &NS::launch_probe_occluded, &NS::launch_probe_detmath}
+#define RAYN_KERNEL_SET(NS) KernelSet{&NS::launch_pack_tables, &NS::launch_raygen, &NS::launch_extend, &NS::launch_group_hist, &NS::launch_scan_tile, &NS::launch_tile_prefix, &NS::launch_bin_scatter, &NS::launch_shade, &NS::launch_compact_scatter, &NS::launch_batch_setup, &NS::launch_resolve, &NS::launch_probe_dist, &NS::launch_shadow_march, &NS::launch_probe_detmath}
 inline KernelSet kernel_set(int fma_policy) {
     if (fma_policy) return RAYN_KERNEL_SET(rayn_p1);
     return RAYN_KERNEL_SET(rayn_p0);

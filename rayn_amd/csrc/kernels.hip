@@ -1788,31 +1788,14 @@ __global__ void __launch_bounds__(256) k_unpack_tiles(const DTile* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// test probes (called through the C ABI by tests only): per-lane primitives on arbitrary inputs
+// test probes (called through the C ABI by tests only): per-lane primitives on arbitrary inputs.  (Closest hit and occlusion have no
+// probe kernel: rayn_hip_probe_extend / rayn_hip_probe_shadow launch the PRODUCT march kernels on a synthetic queue, rayn_hip.hip.)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_probe_dist(const DScene* __restrict__ scp, uint32_t hit_index, const float* __restrict__ pts, float* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     EvalCtr ev;
     out[i] = sdf_dist<false>(scp->h[hit_index], f3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, ev, scp->h[hit_index].scale);
-}
-__global__ void k_probe_closest(const DScene* __restrict__ scp, uint32_t depth, const float* __restrict__ org, const float* __restrict__ dir,
-                                float* __restrict__ out_t, uint32_t* __restrict__ out_obj, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    EvalCtr ev;
-    uint32_t obj;
-    float t;
-    closest_hit<false>(*scp, f3{org[3 * i], org[3 * i + 1], org[3 * i + 2]}, f3{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]},
-                       make_thr(*scp, depth), 0.0f, &t, &obj, ev);
-    out_t[i] = t;
-    out_obj[i] = obj == OBJ_NONE ? INVALID : obj;
-}
-__global__ void k_probe_occluded(const DScene* __restrict__ scp, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    EvalCtr ev;
-    out[i] = test_occluded<false>(*scp, f3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, f3{b[3 * i], b[3 * i + 1], b[3 * i + 2]}, 0.0f, ev);
 }
 __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1912,6 +1895,22 @@ void launch_bin_scatter(hipStream_t s, uint32_t nclass, const uint32_t* q, const
     hipLaunchKernelGGL(k_bin_scatter, stride_grid(max_entries, 256, STREAM_BLOCKS), dim3(256), 0, s, nclass, q, ent_obj, grp_base, grp_tile, tile_out_base, ctl, bq,
                        n_tiles, tile_cls_cnt, tile_total, tile_cls_base);
 }
+// the shadow-march kernel of the scene over the job list in nee / ctl (at most max_jobs entries): k_shade's second stage, and rayn_hip_probe_shadow
+void launch_shadow_march(hipStream_t s, bool count, const DScene* sc, Nee nee, uint32_t max_jobs, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun) {
+    const dim3 grid = stride_grid(max_jobs, 256, tun.persistent_blocks);
+    if (single_sdf >= 0 && tun.fast_path && tun.bulb) {
+#define RAYN_SHADOW_BULB(C, KK, SS) hipLaunchKernelGGL((k_shadow_bulb<C, KK, SS>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.bulb_orbit_min, tun.bulb_prefetch_min, evals + 2)
+        if (count) { if (tun.bulb_rays == 2) RAYN_SHADOW_BULB(true, 2, 1); else if (tun.bulb_rays == 3) RAYN_SHADOW_BULB(true, 3, 1); else RAYN_SHADOW_BULB(true, 4, 1); }
+        else if (tun.bulb_rays == 2) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 2, 2); else RAYN_SHADOW_BULB(false, 2, 1); }
+        else if (tun.bulb_rays == 3) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 3, 2); else RAYN_SHADOW_BULB(false, 3, 1); }
+        else { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 4, 2); else RAYN_SHADOW_BULB(false, 4, 1); }
+#undef RAYN_SHADOW_BULB
+    } else if (single_sdf >= 0 && tun.fast_path) {
+        if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
+        else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
+    } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
+    else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
+}
 void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const float* scramble, uint32_t depth, const uint32_t* bq,
                   uint32_t max_slots, Pool pool, Nee nee, uint32_t ns, bool has_sdf, int single_sdf, unsigned long long* alive_mask, uint8_t* bgrp_cnt, DCtl* ctl,
                   unsigned long long* evals, ShadeHooks hooks, const Tuning& tun) {
@@ -1924,19 +1923,7 @@ void launch_shade(hipStream_t s, bool count, const DScene* sc, Tables tab, const
     if (has_sdf) {
         hooks.before(1);
         hipLaunchKernelGGL(k_shadow_list, stride_grid(ns * max_slots, 256 * SCAN_ITEMS, STREAM_BLOCKS), dim3(256), 0, s, nee, ns, ctl);
-        const dim3 grid = stride_grid(ns * max_slots, 256, tun.persistent_blocks);
-        if (single_sdf >= 0 && tun.fast_path && tun.bulb) {
-#define RAYN_SHADOW_BULB(C, KK, SS) hipLaunchKernelGGL((k_shadow_bulb<C, KK, SS>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.bulb_orbit_min, tun.bulb_prefetch_min, evals + 2)
-            if (count) { if (tun.bulb_rays == 2) RAYN_SHADOW_BULB(true, 2, 1); else if (tun.bulb_rays == 3) RAYN_SHADOW_BULB(true, 3, 1); else RAYN_SHADOW_BULB(true, 4, 1); }
-            else if (tun.bulb_rays == 2) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 2, 2); else RAYN_SHADOW_BULB(false, 2, 1); }
-            else if (tun.bulb_rays == 3) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 3, 2); else RAYN_SHADOW_BULB(false, 3, 1); }
-            else { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 4, 2); else RAYN_SHADOW_BULB(false, 4, 1); }
-#undef RAYN_SHADOW_BULB
-        } else if (single_sdf >= 0 && tun.fast_path) {
-            if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
-            else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
-        } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
-        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
+        launch_shadow_march(s, count, sc, nee, ns * max_slots, single_sdf, ctl, evals, tun);
         hooks.after(1);
     }
     hooks.before(2);
@@ -1977,12 +1964,6 @@ void launch_resolve(hipStream_t s, const DScene* sc, const DTile* tiles, uint32_
 }
 void launch_probe_dist(hipStream_t s, const DScene* sc, uint32_t hit_index, const float* pts, float* out, uint32_t n) {
     hipLaunchKernelGGL(k_probe_dist, grid_for(n, 256), dim3(256), 0, s, sc, hit_index, pts, out, n);
-}
-void launch_probe_closest(hipStream_t s, const DScene* sc, uint32_t depth, const float* org, const float* dir, float* out_t, uint32_t* out_obj, uint32_t n) {
-    hipLaunchKernelGGL(k_probe_closest, grid_for(n, 256), dim3(256), 0, s, sc, depth, org, dir, out_t, out_obj, n);
-}
-void launch_probe_occluded(hipStream_t s, const DScene* sc, const float* a, const float* b, float* out, uint32_t n) {
-    hipLaunchKernelGGL(k_probe_occluded, grid_for(n, 256), dim3(256), 0, s, sc, a, b, out, n);
 }
 void launch_verify_short_div(hipStream_t s, float n, uint32_t lo_bits, uint32_t count, uint32_t* bad) {
     hipLaunchKernelGGL(k_verify_short_div, dim3(4096), dim3(256), 0, s, n, lo_bits, count, bad);

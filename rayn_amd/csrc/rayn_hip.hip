@@ -241,6 +241,17 @@ int build_scene(rayn_ctx* ctx, const rayn_world_desc& w, const rayn_frame_params
     return RAYN_OK;
 }
 
+// which march kernels a scene gets: the index of its TracedSDF when it holds exactly one (single-SDF fast paths), and the context's launch tuning with the
+// per-scene decision Tuning::bulb (a single Mandelbulb marches its shadow segments with march_bulb.h's kernel; the march count shares a register with two flags there)
+int scene_march_kernels(const rayn_ctx* ctx, const DScene& hs, const rayn_frame_params& p, Tuning* tun) {
+    int single_sdf = -1;
+    if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) single_sdf = (int)i;
+    *tun = ctx->tun;
+    tun->bulb = ctx->tun.bulb_path && single_sdf >= 0 && hs.h[single_sdf].sdf_kind == RAYN_SDF_MANDELBULB && hs.h[single_sdf].iterations >= 1 &&
+                p.max_marches < 0xFFFFu && p.max_vis_marches < 0xFFFFu;
+    return single_sdf;
+}
+
 int validate(rayn_ctx* ctx, const rayn_frame_params* p) {
     if (!ctx) return RAYN_ERR_INVALID_ARG;
     if (!p) return fail(ctx, RAYN_ERR_INVALID_ARG, "null frame params");
@@ -599,12 +610,7 @@ int render_device(rayn_ctx* ctx, const rayn_frame_params* p, const float* d_s1, 
     HIPCHK(hipEventRecord(ctx->ev_a, stream));
     HIPCHK(hipMemcpyAsync(ctx->d_scene, &F.hs, sizeof F.hs, hipMemcpyHostToDevice, stream));
     F.K = kernel_set(ctx->fma_policy);
-    F.single_sdf = -1; // index of the TracedSDF when the scene holds exactly one (fast-path kernels)
-    if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) F.single_sdf = (int)i;
-    F.tun = ctx->tun;
-    // a scene whose ONE TracedSDF is a Mandelbulb marches its shadow segments with the kernel written for it (march_bulb.h; the march count shares a register with two flags there)
-    F.tun.bulb = ctx->tun.bulb_path && F.single_sdf >= 0 && hs.h[F.single_sdf].sdf_kind == RAYN_SDF_MANDELBULB && hs.h[F.single_sdf].iterations >= 1 &&
-                 p->max_marches < 0xFFFFu && p->max_vis_marches < 0xFFFFu;
+    F.single_sdf = scene_march_kernels(ctx, hs, *p, &F.tun);
     F.tab = Tables{d_s1, d_s2, d_fis, ctx->d_rec, rec_stride};
     F.K.pack_tables(stream, F.tab, ctx->d_rec, spp, rec_depths, hs.n1, hs.n2);
     F.d_scr = d_scr; F.d_color = d_color; F.d_alpha = d_alpha; F.d_bg = d_bg; F.d_normal = d_normal;
@@ -1198,31 +1204,97 @@ int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t 
     HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RAYN_OK;
 }
-int rayn_hip_probe_closest_hit(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth, const float* org, const float* dir, float* out_t,
-                               uint32_t* out_obj, uint32_t n) {
+// HitableStore::add_hits for caller-supplied rays through the PRODUCT extend kernel of the uploaded scene (k_extend1, or the generic k_extend of a
+// multi-SDF scene): one synthetic ray queue - pool slot i = ray i, queue entry i = i, padded to whole 64-slot groups - one launch, then hit_t / object read back.
+int rayn_hip_probe_extend(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth, const float* org, const float* dir, float* out_t,
+                          uint32_t* out_obj, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
     if (!org || !dir || !out_t || !out_obj) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
+    if (n == 0 || n > (1u << 26)) return fail(ctx, RAYN_ERR_INVALID_ARG, "probe size out of range");
+    DScene hs;
+    rc = build_scene(ctx, ctx->world, *p, &hs);
+    if (rc) return rc;
+    Tuning tun;
+    const int single_sdf = scene_march_kernels(ctx, hs, *p, &tun);
     const KernelSet K = kernel_set(ctx->fma_policy);
-    DevBuf d_o, d_d, d_t, d_obj;
-    HIPCHK(d_o.alloc((size_t)n * 12)); HIPCHK(d_d.alloc((size_t)n * 12)); HIPCHK(d_t.alloc((size_t)n * 4)); HIPCHK(d_obj.alloc((size_t)n * 4));
-    HIPCHK(hipMemcpy(d_o.p, org, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_d.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
-    K.probe_closest(ctx->stream, ctx->d_scene, depth, d_o.as<float>(), d_d.as<float>(), d_t.as<float>(), d_obj.as<uint32_t>(), n);
+    const uint32_t npad = (n + 63u) & ~63u;
+    std::vector<float4> g0(n), g1(n);
+    std::vector<uint32_t> q(npad, INVALID);
+    uint32_t none_bits = OBJ_NONE;
+    float none_f; memcpy(&none_f, &none_bits, 4);
+    for (uint32_t i = 0; i < n; i++) {
+        g0[i] = make_float4(org[3 * i], org[3 * i + 1], org[3 * i + 2], dir[3 * i]);
+        g1[i] = make_float4(dir[3 * i + 1], dir[3 * i + 2], 0.0f, none_f);
+        q[i] = i;
+    }
+    DCtl hc;
+    memset(&hc, 0, sizeof hc);
+    hc.q_groups = npad / 64; hc.q_valid = n;
+    DevBuf d_g0, d_g1, d_c1, d_q, d_obj, d_ctl, d_ev;
+    HIPCHK(d_g0.alloc((size_t)n * 16)); HIPCHK(d_g1.alloc((size_t)n * 16)); HIPCHK(d_c1.alloc((size_t)n * 16)); HIPCHK(d_q.alloc((size_t)npad * 4));
+    HIPCHK(d_obj.alloc(npad)); HIPCHK(d_ctl.alloc(sizeof(DCtl))); HIPCHK(d_ev.alloc(128));
+    HIPCHK(hipMemcpy(d_g0.p, g0.data(), (size_t)n * 16, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_g1.p, g1.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_c1.p, 0, (size_t)n * 16)); // ray time 0 (the packet time of closure-sequenced hitables)
+    HIPCHK(hipMemcpy(d_q.p, q.data(), (size_t)npad * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemset(d_obj.p, 0xEE, npad));
+    HIPCHK(hipMemcpy(d_ctl.p, &hc, sizeof hc, hipMemcpyHostToDevice)); HIPCHK(hipMemset(d_ev.p, 0, 128));
+    Pool pool;
+    memset(&pool, 0, sizeof pool);
+    pool.geo0 = d_g0.as<float4>(); pool.geo1 = d_g1.as<float4>(); pool.col1 = d_c1.as<float4>();
+    K.extend(ctx->stream, false, ctx->d_scene, depth, d_q.as<uint32_t>(), npad, pool, d_obj.as<uint8_t>(), single_sdf, d_ctl.as<DCtl>(), d_ev.as<unsigned long long>(), tun);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(out_t, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_obj, d_obj.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipGetLastError());
+    std::vector<uint8_t> obj(npad);
+    HIPCHK(hipMemcpy(g1.data(), d_g1.p, (size_t)n * 16, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(obj.data(), d_obj.p, npad, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t bits; memcpy(&bits, &g1[i].w, 4);
+        if ((bits & 0xFFu) != obj[i]) return fail(ctx, RAYN_ERR_HIP, "internal: the pool's hit object and the per-entry object byte disagree");
+        out_t[i] = g1[i].z;
+        out_obj[i] = obj[i] == OBJ_NONE ? INVALID : obj[i];
+    }
+    for (uint32_t i = n; i < npad; i++) if (obj[i] != OBJ_NONE) return fail(ctx, RAYN_ERR_HIP, "internal: a padding entry of the queue was not marked empty");
     return RAYN_OK;
 }
-int rayn_hip_probe_occluded(rayn_ctx* ctx, const rayn_frame_params* p, const float* start, const float* end, float* out, uint32_t n) {
+// TracedSDF::occluded of every TracedSDF of the uploaded scene (the SDF factors of HitableStore::test_occluded; the analytic spheres are k_shade_setup's part)
+// for caller-supplied segments through the PRODUCT shadow-march kernel (k_shadow1 / k_shadow_bulb / the generic k_shadow): one synthetic job list, one launch.
+int rayn_hip_probe_shadow(rayn_ctx* ctx, const rayn_frame_params* p, const float* start, const float* end, float* out, uint32_t n) {
     int rc = probe_common(ctx, p);
     if (rc) return rc;
     if (!start || !end || !out) return fail(ctx, RAYN_ERR_INVALID_ARG, "null buffer");
+    if (n == 0 || n > (1u << 26)) return fail(ctx, RAYN_ERR_INVALID_ARG, "probe size out of range");
+    DScene hs;
+    rc = build_scene(ctx, ctx->world, *p, &hs);
+    if (rc) return rc;
+    if (hs.n_sdf == 0) return fail(ctx, RAYN_ERR_INVALID_ARG, "the uploaded world holds no TracedSDF: nothing to march");
+    Tuning tun;
+    const int single_sdf = scene_march_kernels(ctx, hs, *p, &tun);
     const KernelSet K = kernel_set(ctx->fma_policy);
-    DevBuf d_a, d_b, d_out;
-    HIPCHK(d_a.alloc((size_t)n * 12)); HIPCHK(d_b.alloc((size_t)n * 12)); HIPCHK(d_out.alloc((size_t)n * 4));
-    HIPCHK(hipMemcpy(d_a.p, start, (size_t)n * 12, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_b.p, end, (size_t)n * 12, hipMemcpyHostToDevice));
-    K.probe_occluded(ctx->stream, ctx->d_scene, d_a.as<float>(), d_b.as<float>(), d_out.as<float>(), n);
+    std::vector<float2> geo(3 * (size_t)n);
+    std::vector<uint32_t> ref(n);
+    for (uint32_t i = 0; i < n; i++) {
+        geo[3 * (size_t)i] = make_float2(start[3 * i], start[3 * i + 1]);
+        geo[3 * (size_t)i + 1] = make_float2(start[3 * i + 2], end[3 * i]);
+        geo[3 * (size_t)i + 2] = make_float2(end[3 * i + 1], end[3 * i + 2]);
+        ref[i] = i;
+    }
+    DCtl hc;
+    memset(&hc, 0, sizeof hc);
+    hc.job_count = n;
+    DevBuf d_geo, d_ref, d_vis, d_t0, d_ctl, d_ev;
+    HIPCHK(d_geo.alloc((size_t)n * 24)); HIPCHK(d_ref.alloc((size_t)n * 4)); HIPCHK(d_vis.alloc(n)); HIPCHK(d_t0.alloc((size_t)n * 4));
+    HIPCHK(d_ctl.alloc(sizeof(DCtl))); HIPCHK(d_ev.alloc(128));
+    HIPCHK(hipMemcpy(d_geo.p, geo.data(), (size_t)n * 24, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_ref.p, ref.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_vis.p, 2, n)); // every segment pending; the kernels write 1 for a visible one and leave the mark otherwise (= occluded, Nee::vis)
+    HIPCHK(hipMemset(d_t0.p, 0, (size_t)n * 4)); HIPCHK(hipMemcpy(d_ctl.p, &hc, sizeof hc, hipMemcpyHostToDevice)); HIPCHK(hipMemset(d_ev.p, 0, 128));
+    Nee nee;
+    memset(&nee, 0, sizeof nee);
+    nee.vis = d_vis.as<uint8_t>(); nee.t0 = d_t0.as<float>(); nee.cap = n; nee.job_ref = d_ref.as<uint32_t>(); nee.job_geo = d_geo.as<float2>(); nee.jobcap = n;
+    K.shadow_march(ctx->stream, false, ctx->d_scene, nee, n, single_sdf, d_ctl.as<DCtl>(), d_ev.as<unsigned long long>(), tun);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipGetLastError());
+    std::vector<uint8_t> vis(n);
+    HIPCHK(hipMemcpy(vis.data(), d_vis.p, n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) out[i] = vis[i] == 1 ? 1.0f : 0.0f;
     return RAYN_OK;
 }
 int rayn_hip_probe_detmath(rayn_ctx* ctx, uint32_t op, const float* a, const float* b, float* out, uint32_t n) {

@@ -77,6 +77,9 @@ class Context:
         if rc != 0:
             raise RaynHipError(f"rayn_hip error {rc}: {self._L.rayn_hip_last_error(self.h).decode()}")
 
+    def last_error(self):
+        return self._L.rayn_hip_last_error(self.h).decode()
+
     def upload_world(self, desc):
         self._chk(self._L.rayn_hip_upload_world(self.h, C.byref(desc)))
 

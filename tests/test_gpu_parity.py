@@ -135,12 +135,29 @@ def test_mandelbox_dist_bit_exact(gpu_ctx, oracle):
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("name,depth", [("s1", 0), ("s1", 2), ("s0", 0)])
+def _probe_world(name, sdf_only=False):
+    """(world_desc, frame_params) of a probe scene: a SCENES tag, or one of _custom_world's kinds; sdf_only drops the analytic spheres (rayn_hip_probe_shadow
+    marches the TracedSDF factors of HitableStore::test_occluded - the spheres are the shading kernel's part)."""
+    import rayn_amd as R
+    from rayn_amd import params as P
+    from rayn_amd import setup as S
+    if name in S.SCENES:
+        cam, world = S.SCENES[name]((64, 64))
+    else:
+        cam, world = _custom_scene(name, (64, 64))
+    if sdf_only:
+        world.hitables[:] = [h for h in world.hitables if isinstance(h, R.TracedSDF)]
+    return world.to_desc(cam), P.frame_params(64, 64, 1, 3)
+
+
+# the PRODUCT extend kernels (k_extend1 for a single-SDF scene - MandelBox, sphere SDF, Mandelbulb - and the generic k_extend of a multi-SDF scene) on a synthetic queue
+@pytest.mark.parametrize("name,depth", [("s1", 0), ("s1", 2), ("s0", 0), ("bulb", 0), ("bulb", 2), ("two_sdfs", 0), ("two_sdfs", 2)])
 def test_closest_hit_bit_exact(gpu_ctx, oracle, name, depth):
     import ctypes as C
     from rayn_amd._lib import lib
-    wd, p = _probe_setup(gpu_ctx, name)
-    n = 40000
+    wd, p = _probe_world(name)
+    gpu_ctx.upload_world(wd)
+    n = 40000 - 13  # not a multiple of 64: the queue's padding entries
     org = _rand(3 * n, -3.0, 3.0, 11).reshape(-1, 3)
     org[: n // 2] = np.array([-1.0125, 0.45, 4.5], np.float32)  # the shipped camera position
     d = _rand(3 * n, -1.0, 1.0, 12).reshape(-1, 3)
@@ -149,28 +166,31 @@ def test_closest_hit_bit_exact(gpu_ctx, oracle, name, depth):
     t = np.zeros(n, np.float32)
     obj = np.zeros(n, np.uint32)
     fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
-    assert lib().rayn_hip_probe_closest_hit(gpu_ctx.h, C.byref(p), depth, fp(org), fp(d), fp(t), obj.ctypes.data_as(C.POINTER(C.c_uint32)), n) == 0
+    assert lib().rayn_hip_probe_extend(gpu_ctx.h, C.byref(p), depth, fp(org), fp(d), fp(t), obj.ctypes.data_as(C.POINTER(C.c_uint32)), n) == 0, gpu_ctx.last_error()
     rt, robj = oracle.closest_hit(wd, p, depth, org, d)
     assert np.array_equal(obj, robj)
     assert np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    assert len(np.unique(robj)) >= 3  # sky, lights, the SDF(s)
 
 
-def test_occluded_bit_exact(gpu_ctx, oracle):
+# the PRODUCT shadow-march kernels: k_shadow1 (MandelBox, sphere SDF), k_shadow_bulb (Mandelbulb), the generic k_shadow (two SDFs)
+@pytest.mark.parametrize("name", ["s1", "s0", "bulb", "two_sdfs"])
+def test_occluded_bit_exact(gpu_ctx, oracle, name):
     import ctypes as C
     from rayn_amd._lib import lib
-    wd, p = _probe_setup(gpu_ctx, "s1")
-    n = 40000
+    wd, p = _probe_world(name, sdf_only=True)
+    gpu_ctx.upload_world(wd)
+    n = 40000 + 21
     a = _rand(3 * n, -2.0, 2.0, 21).reshape(-1, 3)
     b = _rand(3 * n, -2.0, 2.0, 22).reshape(-1, 3)
     out = np.zeros(n, np.float32)
     fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
-    assert lib().rayn_hip_probe_occluded(gpu_ctx.h, C.byref(p), fp(a), fp(b), fp(out), n) == 0
+    assert lib().rayn_hip_probe_shadow(gpu_ctx.h, C.byref(p), fp(a), fp(b), fp(out), n) == 0, gpu_ctx.last_error()
     ref = oracle.test_occluded(wd, p, a, b)
     assert np.array_equal(out, ref)
     assert 0.02 < ref.mean() < 0.98  # both outcomes exercised
 
 
-# (scene, w, h, samples, bounces, kwargs)
 FILM_CASES = [
     ("s0", 64, 64, 4, 4, {}),                         # BASELINE config 1 shape, scaled
     ("s1", 48, 32, 2, 3, {}),                         # shipped scene, volumes off
@@ -462,7 +482,8 @@ def test_errors_instead_of_panics(gpu_ctx):
 
 
 # ---- the rest of the closed set (SURVEY.md section 8 f/N4): cameras, Lambertian, Box filter, odd scenes ----
-def _custom_world(kind, res):
+def _custom_scene(kind, res):
+    """(camera handle, World) of one of the closed-set test scenes"""
     import rayn_amd as R
     from rayn_amd import setup as S
     from rayn_amd.scene import _mul
@@ -538,6 +559,11 @@ def _custom_world(kind, res):
         world.materials[1] = R.Dielectric.new_remap(R.Srgb(3.0, 3.0, 3.0), 0.6)
     else:
         raise ValueError(kind)
+    return cam_h, world
+
+
+def _custom_world(kind, res):
+    cam_h, world = _custom_scene(kind, res)
     return world.to_desc(cam_h)
 
 
