@@ -127,12 +127,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         # `python bench.py --gpus N` without a launcher: become the driver's own launch line (one rank per GPU under torch.distributed.run).
         # exec, not spawn: same stdout (ONE JSON line from rank 0), same exit code, nothing of this process left behind.
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher's own c10d rendezvous on a port IT picks (no bind-close-reuse race between this process and the launcher)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               os.path.abspath(__file__)] + sys.argv[1:]
         sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: relaunching as `%s`\n" % (args.gpus, " ".join(cmd[1:10]) + " ..."))
         sys.stderr.flush()
         os.execv(sys.executable, cmd)
@@ -159,6 +156,8 @@ def main():
             sys.exit("bench.py: --single-process is one process over N GPUs; do not launch it under torch.distributed.run")
         n_devices = args.gpus
     elif world != args.gpus:
+        if rank == 0:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} disagrees with the launcher's WORLD_SIZE={world}; measuring {world} rank(s)\n")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
@@ -322,10 +321,10 @@ def main():
     paths_per_step = W * H * spp
     value = paths_per_step * args.steps / dt / 1e6
 
-    roofline = None
-    roofline_hbm = None
-    kernel_ms = None
-    if not args.no_roofline and n_devices == 1:
+    def measure_rooflines(scene_tag, workload_tag):
+        """Rooflines of the workload whose world is uploaded in ctx, outside any timed region: (1) one frame with per-kernel-class HIP events on the production kernels
+        (ONE worker: with two, kernels of both streams overlap and their durations stretch), (2) one frame with the instrumented kernel variants (SDF evaluations,
+        fold / orbit iterations, elision and stage accounting).  Returns (roofline, roofline_hbm, kernel_ms)."""
         # (1) per-kernel-class HIP-event timing with the production kernels, (2) SDF-evaluation counts with
         # the instrumented variants.  Both outside the timed region.
         # per-kernel event times are only meaningful without the two-worker overlap: profile with ONE worker
@@ -346,7 +345,7 @@ def main():
         ctx.set_workers(2)
         # flop of the evaluations = per-iteration flop x the iterations the instrumented kernels COUNTED + the per-evaluation part (SDF_FLOPS):
         # exactly 404 per evaluation for the shipped MandelBox; the Mandelbulb's orbits escape early, so its average is below the 682 of 8 full steps
-        sdf_kind = SCENE_SDF[scene]
+        sdf_kind = SCENE_SDF[scene_tag]
         f_it, f_ev = SDF_FLOPS[sdf_kind]
         flops = {k: f_it * it[k] + f_ev * ev[k] for k in ev}
         classes = {"extend": (st["ms_extend"], ev["extend"], st["launches_extend"], flops["extend"]), "shadow": (st["ms_shadow"], ev["shadow"], st["launches_shade"], flops["shadow"]),
@@ -357,10 +356,10 @@ def main():
         flop_per_eval = flop / evals if evals else 0.0
         all_flop = sum(v[3] for v in classes.values())
         frame_tflops = all_flop / (st["ms_total"] * 1e-3) / 1e12 if st["ms_total"] > 0 else 0.0
-        # "bound" names what the kernel is bound by: the FP32 VECTOR pipe (VALU) - nothing here is a dense contraction and no MFMA instruction is
-        # issued; "bound_contract" keeps the bench contract's two-word vocabulary (hbm | mfma = "the compute roof")
-        kname = {"extend": "k_extend1", "shadow": "k_shadow1", "shade_setup": "k_shade_setup"}[dom]
-        roofline = {"kernel": f"{kname} [FP32 VALU-bound; no MFMA instruction is issued anywhere on this path]", "bound": "valu", "bound_contract": "mfma",
+        # "bound" keeps the bench contract's two-word vocabulary (hbm | mfma = "the compute roof"); "bound_unit" names the unit that roof belongs to here:
+        # the FP32 VECTOR pipe (VALU) - nothing on this path is a dense contraction and no MFMA instruction is issued
+        kname = {"extend": "k_extend1", "shadow": "k_shadow_bulb" if sdf_kind == "mandelbulb" else "k_shadow1", "shade_setup": "k_shade_setup"}[dom]
+        roofline = {"kernel": f"{kname} [FP32 VALU-bound; no MFMA instruction is issued anywhere on this path]", "bound": "mfma", "bound_unit": "valu",
                     "bound_detail": "compute-bound on the FP32 VALU (divergent scalar math, no MFMA issued); "
                     "peak = MI355X dense FP32 peak, 157.3 TFLOP/s for the vector pipe and for f32-input MFMA alike",
                     "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
@@ -393,14 +392,14 @@ def main():
             "compact(k_scan_tile+k_tile_prefix+k_compact_scatter)": (st["ms_compact"], st["queue_bytes_compact"]),
             "k_resolve": (st["ms_resolve"], 37.0 * npool + 40.0 * W * H / world),  # col0 + aov + termination record per path, film out
         }
-        qk["k_shadow1 (queue side: 4 B ref + 24 B segment in, 1 B visibility out per shadow job; the kernel itself is VALU-bound)"] = (st["ms_shadow"], 29.0 * st["shadow_jobs"])
+        qk[("k_shadow_bulb" if sdf_kind == "mandelbulb" else "k_shadow1") + " (queue side: 4 B ref + 24 B segment in, 1 B visibility out per shadow job; the kernel itself is VALU-bound)"] = (st["ms_shadow"], 29.0 * st["shadow_jobs"])
         roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shadow_jobs": st["shadow_jobs"], "kernels": {}}
         for name, (ms_k, nbytes) in qk.items():
             ach = nbytes / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
             roofline_hbm["kernels"][name] = {"ms": round(ms_k, 3), "algorithmic_bytes": nbytes, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
         # PMC traffic is measured by separate rocprofv3 --pmc passes (tools/gpu_round.sh) and committed under profiles/ with the
         # hash of the kernel sources it was taken on; a file that does not match the sources of THIS build is not quoted.
-        pmc_name = next((n for n in (f"r05_pmc_hbm_{args.workload}.json", f"r04_pmc_hbm_{args.workload}.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        pmc_name = next((n for n in (f"r06_pmc_hbm_{workload_tag}.json", f"r05_pmc_hbm_{workload_tag}.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         pmc_path = os.path.join(ROOT, "profiles", pmc_name or "")
         if pmc_name and world == 1 and args.fma_policy == 0:
             pj = json.load(open(pmc_path))
@@ -427,6 +426,14 @@ def main():
             else:
                 roofline["traffic_note"] = f"profiles/{pmc_name} was measured on other kernel sources ({pj.get('source_hash')} != {kernel_source_hash()}): not quoted"
         kernel_ms = {k: round(st[k], 3) for k in ("ms_raygen", "ms_extend", "ms_bin", "ms_shade", "ms_shadow", "ms_finish", "ms_compact", "ms_resolve", "ms_total")}
+
+        return roofline, roofline_hbm, kernel_ms
+
+    roofline = None
+    roofline_hbm = None
+    kernel_ms = None
+    if not args.no_roofline and n_devices == 1:
+        roofline, roofline_hbm, kernel_ms = measure_rooflines(scene, args.workload)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and n_devices == 1 and args.cpu_seconds > 0:
@@ -488,10 +495,15 @@ def main():
             torch.cuda.synchronize()
             dt_b = (time.perf_counter() - t_b) / 2
             st_b = ctx.stats()
+            rf_b, rf_hbm_b, kms_b = measure_rooflines(scene_b, "bulb3")
             named = {"workload": desc_b, "value": round(paths_per_step / dt_b / 1e6, 3), "unit": "Mpath-samples/s", "ms_per_step": round(dt_b * 1e3, 3), "steps": 2, "warmup": 1,
                      "segments_per_step": st_b["segments"],
-                     "note": "secondary measurement on the same context after the timed region of `value`; parity of this workload: tests/test_config_digests.py [bulb3]; "
-                             "its own roofline / cpu_baseline: python bench.py --workload bulb3 (profiles/r05_bench_bulb3_*.json)"}
+                     # its OWN roofline: dominant kernel, HIP-event time, counted flop per evaluation; lanes_enabled / traffic from this workload's PMC file
+                     "roofline": {k: rf_b[k] for k in ("kernel", "bound", "bound_unit", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "dist_evals", "sdf",
+                                                       "flop_per_dist_eval", "whole_frame", "bulb_stage_occupancy", "zero_throughput_elision", "lanes_enabled", "valu_issue") if k in rf_b},
+                     "kernel_ms": kms_b,
+                     "note": "secondary measurement on the same context after the timed region of `value` (one warm-up + two timed frames, then one profiling and one counting frame); "
+                             "parity of this workload: tests/test_config_digests.py [bulb3]; cpu_baseline and queue-kernel rooflines: python bench.py --workload bulb3 (profiles/r06_bench_bulb3_*.json)"}
             ctx.upload_world(wd)
         except Exception as e:  # never lose the main line to the secondary measurement
             named = {"error": f"{type(e).__name__}: {e}"}
@@ -522,8 +534,13 @@ def main():
         if per_rank is not None:
             # what the first real multi-GPU run needs to be diagnosable: every rank's render time (HIP events around its share), its
             # gather time, its share of the work; gather_ms = rank 0's (the receiver: pack + collective + scatter of N - 1 blocks)
+            # r6: two keys a driver can plot without post-processing: every rank's render time as a fraction of the slowest rank's (what the launch waits for),
+            # and the share of a step that rank 0 spends in the film gather (collective + unpack, fenced)
+            slowest = max(per_rank["render_ms"]) or 1.0
+            per_rank["frac_of_slowest"] = [round(v / slowest, 4) for v in per_rank["render_ms"]]
             out["per_rank"] = per_rank
             out["gather_ms"] = per_rank["gather_ms"][0]
+            out["gather_share_of_step"] = round(per_rank["gather_ms"][0] / max(dt / args.steps * 1e3, 1e-9), 5)
             mean_r = sum(per_rank["render_ms"]) / len(per_rank["render_ms"])
             out["imbalance"] = round(max(per_rank["render_ms"]) / mean_r, 4) if mean_r > 0 else None
         if n_devices > 1:
@@ -532,7 +549,9 @@ def main():
             rms = [d["render_ms"] / args.steps for d in dev_acc]
             out["per_device"] = {"render_ms": [round(v, 3) for v in rms], "segments": [d["segments"] for d in dev_acc], "batches": [d["batches"] for d in dev_acc],
                                  "tiles": [d["tiles"] for d in dev_acc]}
+            out["per_device"]["frac_of_slowest"] = [round(v / (max(rms) or 1.0), 4) for v in rms]
             out["exchange_ms"] = round(acc["render_ms"] / args.steps - max(rms), 3)
+            out["exchange_share_of_step"] = round(out["exchange_ms"] / max(dt / args.steps * 1e3, 1e-9), 5)
             mean_r = sum(rms) / len(rms)
             out["imbalance"] = round(max(rms) / mean_r, 4) if mean_r > 0 else None
         if film_check is not None:

@@ -200,6 +200,11 @@ int rayn_hip_create(int device, rayn_ctx** out);
  * RAYN_ERR_INVALID_ARG on a multi-device ctx. */
 int rayn_hip_create_multi(const int* devices, int n_devices, rayn_ctx** out);
 int rayn_hip_device_count(const rayn_ctx* ctx); /* entries of the context (1 for rayn_hip_create) */
+/* Multi-device context: the sample tables / scramble / filter table are copied to every peer when a frame's (four table pointers, width, height, samples,
+ * max_bounces, volume_marches, frame) differ from the last broadcast to that peer - not every frame (r6).  A host that REWRITES its tables in place under
+ * unchanged parameters calls rayn_hip_upload_world again (it forgets the broadcast) or passes other buffers.  Returns the peer copies of the tables made so
+ * far (one per peer and broadcast; diagnostics / tests). */
+uint64_t rayn_hip_table_broadcasts(const rayn_ctx* ctx);
 void rayn_hip_destroy(rayn_ctx* ctx);
 const char* rayn_hip_last_error(const rayn_ctx* ctx);
 

@@ -30,7 +30,7 @@ def _lib_path():
 
 # every symbol include/rayn_hip.h declares
 EXPORTS = [
-    "rayn_hip_create", "rayn_hip_create_multi", "rayn_hip_device_count", "rayn_hip_destroy", "rayn_hip_last_error", "rayn_hip_upload_world", "rayn_hip_render_frame",
+    "rayn_hip_create", "rayn_hip_create_multi", "rayn_hip_device_count", "rayn_hip_table_broadcasts", "rayn_hip_destroy", "rayn_hip_last_error", "rayn_hip_upload_world", "rayn_hip_render_frame",
     "rayn_hip_render_frame_device", "rayn_hip_get_stats", "rayn_sets_1d", "rayn_sets_2d", "rayn_build_rd_tables",
     "rayn_build_scramble", "rayn_build_fis_table", "rayn_build_fis_table_ex", "rayn_tile_count", "rayn_hip_set_profiling", "rayn_hip_get_eval_counts",
     "rayn_hip_set_batch_paths", "rayn_hip_set_cold_bytes", "rayn_hip_set_workers", "rayn_hip_set_tile_subset", "rayn_hip_set_trace_tile", "rayn_hip_get_trace", "rayn_hip_fma_policy", "rayn_hip_set_fma_policy", "rayn_hip_sizeof", "rayn_hip_probe_sdf_dist",
@@ -68,6 +68,8 @@ def lib():
         L.rayn_hip_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.rayn_hip_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
         L.rayn_hip_device_count.argtypes = [vp]
+        L.rayn_hip_table_broadcasts.argtypes = [vp]
+        L.rayn_hip_table_broadcasts.restype = C.c_uint64
         L.rayn_hip_destroy.argtypes = [vp]
         L.rayn_hip_destroy.restype = None
         L.rayn_hip_last_error.argtypes = [vp]

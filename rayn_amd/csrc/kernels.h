@@ -13,10 +13,15 @@ constexpr uint32_t SCAN_NC_BIN = 16; // = RAYN_MAX_HITABLES: classes of the bin 
 // resolve_keys_fit() is checked by the host for every frame share (run_worker): relaxing the host's tile / spp limits cannot silently spill the offset into the depth bits
 // (which would change the summation order) - it becomes an error instead.
 constexpr uint32_t RESOLVE_KEY_SHIFT = 25;
-static_assert(120u < (1u << (32 - RESOLVE_KEY_SHIFT)) - 1u, "depth field of the resolve key too narrow for max_bounces <= 120 (0x7F.. is NOKEY's prefix)");
-inline bool resolve_keys_fit(uint32_t max_tile_pixels, uint32_t spp) {
+static_assert(120u < (1u << (32 - RESOLVE_KEY_SHIFT)) - 1u, /* MAX_BOUNCES below */ "depth field of the resolve key too narrow for max_bounces <= 120 (0x7F.. is NOKEY's prefix)");
+constexpr bool resolve_keys_fit(uint32_t max_tile_pixels, uint32_t spp) {
     return (unsigned long long)max_tile_pixels * spp + SCAN_NC_BIN * 3ull + 64ull < (1ull << RESOLVE_KEY_SHIFT);
 }
+// the limits validate() enforces (rayn_hip.hip): tiles of at most 1024 pixels; k_resolve_blk serves 512 < spp <= 4096.  Under them the check cannot fail -
+// it guards a future relaxation of either limit (then: a compile error here, or the per-frame error in run_worker for the combination that does not fit)
+constexpr uint32_t MAX_TILE_PIXELS = 1024, MAX_SPP_RESOLVE_BLK = 4096, MAX_BOUNCES = 120;
+static_assert(resolve_keys_fit(MAX_TILE_PIXELS, MAX_SPP_RESOLVE_BLK), "k_resolve_blk's 25-bit slot offset does not cover the largest tile x spp the host accepts");
+static_assert(!resolve_keys_fit(MAX_TILE_PIXELS, 8u * MAX_SPP_RESOLVE_BLK), "resolve_keys_fit must reject a segment beyond 2^25 slots");
 
 
 // Path pool (device pointers): one slot per camera path, records of 16 bytes so that a scattered

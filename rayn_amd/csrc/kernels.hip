@@ -1477,11 +1477,11 @@ __global__ void __launch_bounds__(NT) k_resolve_blk(const DScene* __restrict__ s
     const size_t fi = film_pixel(tile, lpix, sc.width);
     const float n = (float)spp;
     // ---- Color / Background in (depth, slot) order.  r4: the sort runs on 32-bit keys WITHOUT a payload - depth:7 | slot relative to
-    // where the tile's binned segment began at that depth (k_tile_prefix keeps those bases per depth; a tile's segment is < 2^23 slots for
-    // <= 1024 pixels x 4096 spp, the offset field has RESOLVE_KEY_SHIFT = 25 bits and the host refuses a frame that could exceed it: resolve_keys_fit, kernels.h) - and every sample then finds its rank in the sorted key array by binary search (keys of a pixel are
+    // where the tile's binned segment began at that depth (k_tile_prefix keeps those bases per depth; a tile's segment is at most
+    // 1024 pixels x 4096 spp + padding = 2^22 + 112 slots, the offset field has RESOLVE_KEY_SHIFT = 25 bits, checked at compile time against the host's limits and per frame: resolve_keys_fit, kernels.h) - and every sample then finds its rank in the sorted key array by binary search (keys of a pixel are
     // distinct: a slot holds one path).  Half the registers, one shuffle + v_cmp + v_cndmask per compare-exchange instead of two shuffles,
     // a 64-bit compare and two selects.
-    constexpr uint32_t NOKEY = 0xFFFFFFFFu; // depth <= 120: no real key has the top bit set
+    constexpr uint32_t NOKEY = 0xFFFFFFFFu; // keys compare UNSIGNED; depth <= 120 (validate()) puts every real key below 121 << 25 = 0xF2000000 < NOKEY (depths >= 64 do set bit 31)
     uint32_t ko[KPL];
     uint32_t mine = 0, bgm = 0;
 #pragma unroll

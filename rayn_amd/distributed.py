@@ -58,6 +58,7 @@ class FilmGather:
         self.rank, self.world, self.n_pixels = rank, world, width * height
         self.width, self.height, self.tile = width, height, (int(tile_size[0]), int(tile_size[1]))
         self.ctx, self.device = ctx, device
+        self._unpack_stream = None  # rank 0, device films: the stream the unpack launches run on (created on first use)
         if ctx is not None:
             from .film import share_pixels
             assert params is not None and (params.width, params.height, params.tile_w, params.tile_h) == (width, height) + self.tile
@@ -105,8 +106,9 @@ class FilmGather:
             film[ch].view(self.n_pixels, -1)[idx] = block[off * n:(off + k) * n].view(n, k)
 
     def gather(self, film, group=None):
-        """One collective per frame: every rank's packed block goes to rank 0, which writes the blocks into ITS film (returned on
-        rank 0, complete; None elsewhere)."""
+        """One collective per frame: every rank's packed block goes to rank 0, which writes the blocks into ITS film (returned on rank 0, None
+        elsewhere).  A device film is returned STREAM-ORDERED on torch's current stream, not host-complete: work enqueued on that stream afterwards
+        sees every pixel; a host read needs the usual synchronise."""
         import torch.distributed as dist
         if self.world == 1 and not self.force:
             return film
@@ -120,18 +122,26 @@ class FilmGather:
             return None
         if self.stage_host:
             self.recv_dev.copy_(self.recv_all)
+        ustream = None
         if self.ctx is not None:
-            # dist.gather returned once the collective was ENQUEUED (ProcessGroupNCCL makes torch's current stream wait for it, not the
-            # host), and the unpack kernels run on the stream the library is given - its own when torch's current stream is the null
-            # stream.  Wait for the blocks here rather than rely on legacy-null-stream ordering between the two: the frame cannot be
-            # complete before the gather is, so the wait costs nothing that the frame's final synchronise would not pay.
+            # dist.gather returned once the collective was ENQUEUED: ProcessGroupNCCL makes torch's CURRENT stream wait for it, not the host.  The unpack
+            # kernels therefore run on a stream of this object that first waits for torch's current stream (= for the collective), and torch's current
+            # stream waits for that stream after the last unpack: the returned film is STREAM-ORDERED on torch's current stream - complete for every
+            # consumer on it (and for the next frame's gather, which ProcessGroupNCCL orders after the current stream, so `recv_all` is not overwritten
+            # under a running unpack) - without a host wait and without relying on legacy null-stream semantics.
             import torch
-            torch.cuda.current_stream().synchronize()
+            if self._unpack_stream is None:
+                self._unpack_stream = torch.cuda.Stream(device=self.device)
+            ustream = self._unpack_stream
+            ustream.wait_stream(torch.cuda.current_stream())
         for r in range(0 if self.force else 1, self.world):
             if self.counts[r] == 0:
                 continue
             if self.ctx is not None:
-                self.ctx.unpack_share(self.share_params[r], self.recv_dev[r], film)
+                self.ctx.unpack_share(self.share_params[r], self.recv_dev[r], film, stream=ustream.cuda_stream)
             else:
                 self._scatter_indexed(film, r, self.recv_dev[r])
+        if ustream is not None:
+            import torch
+            torch.cuda.current_stream().wait_stream(ustream)
         return film

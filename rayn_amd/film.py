@@ -77,6 +77,10 @@ class Context:
         if rc != 0:
             raise RaynHipError(f"rayn_hip error {rc}: {self._L.rayn_hip_last_error(self.h).decode()}")
 
+    def table_broadcasts(self):
+        """multi-device context: peer copies of the sample tables made so far (rayn_hip_table_broadcasts)"""
+        return int(self._L.rayn_hip_table_broadcasts(self.h))
+
     def last_error(self):
         return self._L.rayn_hip_last_error(self.h).decode()
 

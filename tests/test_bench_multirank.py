@@ -50,6 +50,9 @@ def _check_per_rank(out, ranks):
     assert sum(pr["segments"]) == out["segments_per_step"] and all(b >= 1 for b in pr["batches"])
     assert out["gather_ms"] == pr["gather_ms"][0] and out["gather_ms"] > 0
     assert 1.0 <= out["imbalance"] < 10.0
+    # r6: plot-ready keys - every rank's render time over the slowest rank's, the gather's share of a step
+    assert len(pr["frac_of_slowest"]) == ranks and max(pr["frac_of_slowest"]) == 1.0 and all(0 < v <= 1.0 for v in pr["frac_of_slowest"])
+    assert 0 < out["gather_share_of_step"] < 1.0 and abs(out["gather_share_of_step"] - out["gather_ms"] / out["ms_per_step"]) < 1e-3
     # the ranks' own clocks must explain the line: slowest render + its gather <= the max-over-ranks step time (+ slack for the barrier)
     assert max(pr["render_wall_ms"]) <= out["ms_per_step"] * 1.05 + 1.0
 
@@ -110,7 +113,7 @@ def test_bench_line_contract_n1():
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f32" and out["vs_baseline"] is None
     assert out["value"] > 0 and abs(out["value"] - out["config"]["paths_per_step"] / out["ms_per_step"] / 1e3) < 1e-2 * out["value"]
     rf = out["roofline"]
-    assert rf["bound"] == "valu" and rf["bound_contract"] in ("hbm", "mfma") and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["bound"] in ("hbm", "mfma") and rf["bound_unit"] == "valu" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "k_extend1" in rf["kernel"] or "k_shadow1" in rf["kernel"] or "k_shade_setup" in rf["kernel"]
     # the flop of an evaluation comes from COUNTED iterations: the MandelBox always runs its 12 folds -> exactly 33 x 12 + 8
     assert rf["sdf"] == "mandelbox" and rf["flop_per_dist_eval"] == 404.0 and rf["sdf_iterations"] == 12 * rf["dist_evals"]
@@ -137,6 +140,13 @@ def test_bench_bulb_prices_the_mandelbulb_by_counted_iterations():
     rf = out["roofline"]
     assert rf["sdf"] == "mandelbulb" and 84.0 + 10.0 <= rf["flop_per_dist_eval"] < 682.0
     assert rf["dist_evals"] <= rf["sdf_iterations"] <= 8 * rf["dist_evals"]
+    # r6: the scene's shadow segments are marched by k_shadow_bulb (march_bulb.h); the line carries the occupancy of its two stages and the elision accounting
+    occ = rf["bulb_stage_occupancy"]["k_shadow_bulb"]
+    assert 0.3 < occ["orbit"] <= 1.0 and 0.3 < occ["epilogue"] <= 1.0
+    el = rf["zero_throughput_elision"]
+    assert el["zero_throughput_slots"] > 0 and el["shadow_jobs_marched"] > 0 and 0 < el["share_of_segments"] < 0.5
+    if "k_shadow" in rf["kernel"]:
+        assert "k_shadow_bulb" in rf["kernel"]
 
 
 @pytest.mark.gpu
@@ -179,6 +189,7 @@ def test_bench_single_process_multi_device(entries):
     assert len(pd["render_ms"]) == entries and all(v > 0 for v in pd["render_ms"]) and sum(pd["tiles"]) == 256
     assert sum(pd["segments"]) == out["segments_per_step"] == json.load(open(os.path.join(ROOT, "tests", "golden", "config_digests.json")))["c1"]["frame_counts"]["segments"]
     assert max(pd["render_ms"]) <= out["ms_per_step"] * 1.05 + 1.0 and out["exchange_ms"] > -1.0
+    assert max(pd["frac_of_slowest"]) == 1.0 and abs(out["exchange_share_of_step"] - out["exchange_ms"] / out["ms_per_step"]) < 1e-3
 
 
 @pytest.mark.gpu
@@ -195,6 +206,11 @@ def test_bench_default_line_carries_the_named_workload():
     assert "error" not in nw, nw
     assert nw["workload"] == "small bulb3 (test)" and nw["value"] > 0 and nw["steps"] == 2 and nw["segments_per_step"] >= out["config"]["paths_per_step"]
     assert out["config"]["workload"] == "small c3 (test)" and out["roofline"]["sdf"] == "mandelbox"
+    # r6: the named workload carries its OWN roofline - dominant kernel, fraction, counted flop per evaluation of ITS SDF - and kernel times
+    nrf = nw["roofline"]
+    assert nrf["sdf"] == "mandelbulb" and nrf["bound"] in ("hbm", "mfma") and 0 < nrf["frac"] < 1 and 94.0 <= nrf["flop_per_dist_eval"] < 682.0
+    assert nrf["bulb_stage_occupancy"]["k_shadow_bulb"]["orbit"] > 0.3 and nw["kernel_ms"]["ms_shadow"] > 0
+    assert out["roofline"]["bulb_stage_occupancy"] is None  # the MandelBox frame runs k_shadow1
     # and the secondary measurement is off where it does not belong
     code2 = code.replace("'--no-cold']", "'--no-cold', '--no-named']")
     r2 = subprocess.run([sys.executable, "-c", code2], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)

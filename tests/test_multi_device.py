@@ -84,3 +84,50 @@ def test_multi_ctx_against_oracle_and_device_buffers(oracle):
         assert np.all(a[~owned] == 7.0) and np.array_equal(a[owned].view(np.uint32), ref["alpha"][owned].view(np.uint32))
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+def test_tables_are_broadcast_once_per_key(oracle):
+    """r6: the peers' copies of the sample tables are made when the frame's (table buffers, resolution, samples, bounces, volume marches, frame) change - not
+    every frame.  Three entries = two peers: two peer copies for the first frame, none for a repeat, two more after another frame number (other tables in the
+    SAME device buffers would go unnoticed: the host then re-uploads the world, which forgets the broadcast), every film equal to the oracle's."""
+    import torch
+    import rayn_amd
+    W, H = 64, 48
+    wd, p = case("s1", W, H, 2, 3)
+    m = rayn_amd.Context([0, 0, 0])
+    try:
+        m.upload_world(wd)
+        film = rayn_amd.film.alloc_device_film(W, H, "cuda:0")
+
+        def frame(p, d_tabs, ref):
+            m.render_device(p, d_tabs, film)
+            torch.cuda.synchronize()
+            out = {"color": film["color"].cpu().numpy().reshape(H, W, 3), "alpha": film["alpha"].cpu().numpy().reshape(H, W),
+                   "background": film["background"].cpu().numpy().reshape(H, W, 3), "normal": film["normal"].cpu().numpy().reshape(H, W, 3)}
+            assert film_equal_bits(out, ref)
+
+        tabs = oracle.build_tables(4 * p.samples, p.max_bounces, p.volume_marches, p.frame, W, H)
+        ref, _ = oracle.render(wd, p, tabs)
+        d_tabs = [torch.from_numpy(t).cuda() for t in tabs]
+        assert m.table_broadcasts() == 0
+        frame(p, d_tabs, ref)
+        assert m.table_broadcasts() == 2
+        frame(p, d_tabs, ref)
+        frame(p, d_tabs, ref)
+        assert m.table_broadcasts() == 2
+        p2 = case("s1", W, H, 2, 3, frame=5)[1]
+        tabs2 = oracle.build_tables(4 * p2.samples, p2.max_bounces, p2.volume_marches, p2.frame, W, H)
+        ref2, _ = oracle.render(wd, p2, tabs2)
+        for dst, src in zip(d_tabs, tabs2):  # the new frame's tables in the SAME device buffers: the frame number is part of the key
+            dst.copy_(torch.from_numpy(src))
+        frame(p2, d_tabs, ref2)
+        assert m.table_broadcasts() == 4
+        for dst, src in zip(d_tabs, tabs):  # rewritten in place under an unchanged key: the documented way to say so is another upload_world
+            dst.copy_(torch.from_numpy(src))
+        p2.frame = p.frame
+        m.upload_world(wd)
+        frame(p2, d_tabs, ref)
+        assert m.table_broadcasts() == 6
+    finally:
+        m.close()
