@@ -280,10 +280,13 @@ RD float sdf_scale(const DHitable& h, float t0) { return h.scale_vel != 0.0f ? h
 // |c| <= |l| <= 2^60: the product 2c is exact, so ONE rounding (fma) == the reference's two (mul, add)
 #define RAYN_BOX_FMA(c, q) __builtin_fmaf(c, 2.0f, -(q))
 #define RAYN_FOLD_X4(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX)
-template <bool COUNT>
+// SDFK >= 0: the SDF kind is known at compile time (the single-SDF march kernels are instantiated per kind: no per-evaluation branch, and the registers
+// / scalar constants of the other SDFs are not carried through the march loop); -1: the kind is read from the object
+template <bool COUNT, int SDFK = -1>
 RD float sdf_dist(const DHitable& h, f3 p, EvalCtr& evals, float scale) {
-    if (COUNT) { evals.n++; evals.it += h.sdf_kind == RAYN_SDF_SPHERE ? 0u : h.iterations; } // the Mandelbulb takes its early exits off again (mandelbulb_dist)
-    if (h.sdf_kind == RAYN_SDF_MANDELBOX) {
+    const uint32_t kind = SDFK >= 0 ? (uint32_t)SDFK : h.sdf_kind;
+    if (COUNT) { evals.n++; evals.it += kind == RAYN_SDF_SPHERE ? 0u : h.iterations; } // the Mandelbulb takes its early exits off again (mandelbulb_dist)
+    if (kind == RAYN_SDF_MANDELBOX) {
         const f3 offset = p;
         float dr = 1.0f;
         const float l = h.box_l, nl = -h.box_l, s = scale;
@@ -311,7 +314,7 @@ RD float sdf_dist(const DHitable& h, f3 p, EvalCtr& evals, float scale) {
         }
         return mag(p) / __builtin_fabsf(dr);
     }
-    if (h.sdf_kind == RAYN_SDF_MANDELBULB) return mandelbulb_dist<COUNT>(p, h.iterations, evals);
+    if (kind == RAYN_SDF_MANDELBULB) return mandelbulb_dist<COUNT>(p, h.iterations, evals);
     return mag(p) - h.sdf_radius;
 }
 #undef RAYN_FOLD_X4

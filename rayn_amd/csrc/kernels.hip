@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) k_extend(const DScene* __restrict__ scp, 
 //    its march stores the result and starts the next ray in the same loop trip.  The queue fetch runs in
 //    bulk when >= PREFETCH_MIN lanes have used up their spare ray, so lanes idle only at the very end.
 // ------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, int SDFK>
 __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp, uint32_t depth, uint32_t ks, const uint32_t* __restrict__ q,
                                                   DCtl* __restrict__ ctl, Pool pool, uint8_t* __restrict__ ent_obj,
                                                   uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
         }
         if (c_has) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
             const f3 p = first ? o : muladd3(d, t, o);
-            const float dist = sdf_dist<COUNT>(h, p, evals, c_scale);
+            const float dist = sdf_dist<COUNT, SDFK>(h, p, evals, c_scale);
             bool done;
             if (first) { t = dist; nan = dist != dist; first = false; m = 0; done = max_marches == 0; }
             else {
@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(256) k_shadow(const DScene* __restrict__ scp, 
 // Fast path of k_shadow for scenes with exactly one TracedSDF: uniform SDF parameters, and a
 // prefetched NEXT segment per lane (see k_extend1).  (A variant that scans the visibility bytes itself instead of consuming
 // k_shadow_list's job list was measured 1-4 % slower - window logic + 8 VGPRs in the hot loop; tools/variants/README.md.)
-template <bool COUNT>
+template <bool COUNT, int SDFK>
 __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp, uint32_t ks, Nee nee, DCtl* __restrict__ ctl,
                                                   uint32_t PREFETCH_MIN, unsigned long long* __restrict__ evals_out) {
     const DScene& sc = *scp;
@@ -1116,7 +1116,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
         }
         if (c_has) { // TracedSDF::occluded, src/sdf.rs:25-57
             const f3 p = first ? start : muladd3(dir, t, start);
-            const float dist = sdf_dist<COUNT>(h, p, evals, c_scale);
+            const float dist = sdf_dist<COUNT, SDFK>(h, p, evals, c_scale);
             int res = -1; // -1 keep marching, 0 occluded, 1 visible
             if (first) {
                 t = dist; nan = dist != dist; first = false; m = 0;
@@ -1870,8 +1870,13 @@ void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, 
                    uint8_t* ent_obj, int single_sdf, DCtl* ctl, unsigned long long* evals, const Tuning& tun) {
     const dim3 grid = stride_grid(max_entries, 256, tun.persistent_blocks);
     if (single_sdf >= 0 && tun.fast_path) { // (a single-Mandelbulb scene keeps k_extend1 for its closest-hit marches: the k_shadow_bulb scheme measured slower here, tools/variants/r6_k_extend_bulb.h)
-        if (count) hipLaunchKernelGGL(k_extend1<true>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
-        else hipLaunchKernelGGL(k_extend1<false>, grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals);
+        // one instantiation per SDF kind of the scene's single TracedSDF (Tuning::sdf_kind, set per frame by the host); the counting variants stay generic
+#define RAYN_EXTEND1(C, KIND) hipLaunchKernelGGL((k_extend1<C, KIND>), grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals)
+        if (count) RAYN_EXTEND1(true, -1);
+        else if (tun.sdf_kind == RAYN_SDF_MANDELBOX) RAYN_EXTEND1(false, RAYN_SDF_MANDELBOX);
+        else if (tun.sdf_kind == RAYN_SDF_MANDELBULB) RAYN_EXTEND1(false, RAYN_SDF_MANDELBULB);
+        else RAYN_EXTEND1(false, -1);
+#undef RAYN_EXTEND1
     } else if (count) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
     else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, s, sc, depth, q, ctl, pool, ent_obj, tun.refill_min_extend, evals);
 }
@@ -1906,8 +1911,11 @@ void launch_shadow_march(hipStream_t s, bool count, const DScene* sc, Nee nee, u
         else { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 4, 2); else RAYN_SHADOW_BULB(false, 4, 1); }
 #undef RAYN_SHADOW_BULB
     } else if (single_sdf >= 0 && tun.fast_path) {
-        if (count) hipLaunchKernelGGL(k_shadow1<true>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
-        else hipLaunchKernelGGL(k_shadow1<false>, grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2);
+#define RAYN_SHADOW1(C, KIND) hipLaunchKernelGGL((k_shadow1<C, KIND>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2)
+        if (count) RAYN_SHADOW1(true, -1);
+        else if (tun.sdf_kind == RAYN_SDF_MANDELBOX) RAYN_SHADOW1(false, RAYN_SDF_MANDELBOX);
+        else RAYN_SHADOW1(false, -1); // (sphere SDF; a Mandelbulb scene with the k_shadow_bulb path switched off)
+#undef RAYN_SHADOW1
     } else if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
     else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(256), 0, s, sc, nee, ctl, tun.refill_min_shadow, evals + 2);
 }

@@ -254,6 +254,7 @@ int scene_march_kernels(const rayn_ctx* ctx, const DScene& hs, const rayn_frame_
     int single_sdf = -1;
     if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) single_sdf = (int)i;
     *tun = ctx->tun;
+    tun->sdf_kind = single_sdf >= 0 && ctx->tun.sdf_templates ? (int)hs.h[single_sdf].sdf_kind : -1;
     tun->bulb = ctx->tun.bulb_path && single_sdf >= 0 && hs.h[single_sdf].sdf_kind == RAYN_SDF_MANDELBULB && hs.h[single_sdf].iterations >= 1 &&
                 p.max_marches < 0xFFFFu && p.max_vis_marches < 0xFFFFu;
     return single_sdf;
@@ -935,6 +936,7 @@ int rayn_hip_create(int device, rayn_ctx** out) {
         if (const char* e = getenv("RAYN_HIP_PREFETCH_SHADOW")) ctx->tun.prefetch_min_shadow = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("RAYN_HIP_FAST_PATH")) ctx->tun.fast_path = atoi(e) != 0;
         if (const char* e = getenv("RAYN_HIP_PERSISTENT_BLOCKS")) ctx->tun.persistent_blocks = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = getenv("RAYN_HIP_SDF_TEMPLATES")) ctx->tun.sdf_templates = atoi(e) != 0;
         if (const char* e = getenv("RAYN_HIP_BULB_PATH")) ctx->tun.bulb_path = atoi(e) != 0;
         if (const char* e = getenv("RAYN_HIP_BULB_STEPS")) ctx->tun.bulb_steps = atoi(e) == 2 ? 2u : 1u;
         if (const char* e = getenv("RAYN_HIP_BULB_ORBIT_MIN")) ctx->tun.bulb_orbit_min = (uint32_t)std::max(0, atoi(e));

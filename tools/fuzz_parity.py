@@ -1,7 +1,8 @@
 """Hunt for rare GPU/oracle mismatches: N seeded random scenes (the generator of tests/test_gpu_parity.py's
 test_randomised_scene_parity, larger films, up to 1024 spp).  Every third scene goes through a two-entry multi-device context
 (rayn_hip_create_multi on GPU 0 twice); r5: every third OTHER scene is rendered share by share (2-5 ranks' shares) straight into the packed planar
-films of the multi-process gather and reassembled with rayn_hip_unpack_share_device.  usage: fuzz_parity.py [n=60] [first_seed=100]"""
+films of the multi-process gather and reassembled with rayn_hip_unpack_share_device.  r6: a third argument `bulb` makes every scene a Mandelbulb
+scene (k_shadow_bulb, march_bulb.h) with random march budgets.  usage: fuzz_parity.py [n=60] [first_seed=100] [bulb]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -11,6 +12,7 @@ from rayn_amd import setup as S, params as P
 from oracle import oracle_py as O
 from common import film_equal_bits, film_l2
 n, first = (int(sys.argv[1]) if len(sys.argv) > 1 else 60), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+only_bulb = len(sys.argv) > 3 and sys.argv[3] == "bulb"
 ctx1 = R.Context(0)
 ctx2 = R.Context([0, 0])
 bad = 0
@@ -20,6 +22,8 @@ for seed in range(first, first + n):
     w, h = int(rng.integers(32, 97)), int(rng.integers(24, 65))
     volumes = bool(rng.integers(0, 2))
     kind = rng.choice(["mandelbox", "mandelbox", "mandelbox", "mandelbulb", "sphere"])
+    if only_bulb:
+        kind = "mandelbulb"
     cam_h, world = S.setup((w, h), volumes=volumes, sdf=str(kind))
     if kind == "mandelbox":
         box = world.hitables[1].sdf
@@ -40,13 +44,16 @@ for seed in range(first, first + n):
         world.hitables[1].transform_seq = R.Linear(rng.uniform(-0.3, 0.3, 3).astype(np.float32), rng.uniform(-4, 4, 3).astype(np.float32))
     if rng.integers(0, 4) == 0:
         cam.origin = R.Linear(cam.origin, rng.uniform(-3, 3, 3).astype(np.float32))
+    if only_bulb:
+        world.hitables[1].sdf.iterations = int(rng.integers(1, 13))
     wd = world.to_desc(cam_h)
     samples, bounces = int(rng.choice([1, 2, 3, 4, 4, 8, 16, 33, 64, 150, 256])), int(rng.integers(0, 9))
     if samples >= 8:  # many samples per pixel (the resolve sorts 4*samples keys): keep the film small
         w, h = max(8, w // (samples // 4 + 1)), max(6, h // 4)
     t0 = float(np.float32(rng.uniform(0.0, 3.0)))
     p = P.frame_params(w, h, samples, bounces, frame=int(rng.integers(1, 200)), time_range=(t0, float(np.float32(t0 + rng.uniform(0.005, 0.3)))),
-                       tile_size=(int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))), volume_marches=int(rng.choice([2, 2, 3, 4])))
+                       tile_size=(int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))), volume_marches=int(rng.choice([2, 2, 3, 4])),
+                       **({"max_marches": int(rng.choice([256, 256, 40, 3])), "max_vis_marches": int(rng.choice([100, 100, 12, 1]))} if only_bulb else {}))
     tabs = O.build_tables(4 * samples, bounces, p.volume_marches, p.frame, w, h)
     ref, ctr = O.render(wd, p, tabs)
     ctx = ctx2 if seed % 3 == 0 else ctx1

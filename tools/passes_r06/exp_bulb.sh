@@ -7,7 +7,7 @@ mkdir -p gpurun_out; : > $OUT
 [ -n "$SKIP_TESTS" ] || timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_config_digests.py -m gpu -x -q -k "bulb" 2>&1 | tail -3 >> $OUT
 run() { # label, env...
   label=$1; shift
-  line=$(env "$@" timeout 400 python bench.py --workload bulb3 --steps 1 --warmup 1 --no-cold --cpu-seconds 0 2>&1 | tail -1)
+  line=$(env "$@" timeout 400 python bench.py --workload ${WL:-bulb3} --steps ${STEPS:-1} --warmup 1 --no-cold --cpu-seconds 0 2>&1 | tail -1)
   echo "$label $(echo "$line" | python -c "
 import json,sys
 try:
