@@ -29,6 +29,7 @@
 #define RAYN_DETMATH_FAST_H
 
 #include "rayn_detmath.h"
+#include "rayn_logtab.h"
 
 #if defined(__HIPCC__) && defined(DMF_NOINLINE)
 #define RAYN_SLOW static __host__ __device__ __attribute__((noinline))
@@ -51,6 +52,7 @@ RAYN_SLOW float dmf_slow_pow(float x, float y) { DMF_NOTE_FALLBACK; return dm_po
 RAYN_SLOW void dmf_slow_sincos(float x, float* s, float* c) { DMF_NOTE_FALLBACK; dm_sincosf(x, s, c); }
 RAYN_SLOW float dmf_slow_tan(float x) { DMF_NOTE_FALLBACK; return dm_tanf(x); }
 RAYN_SLOW float dmf_slow_atan2(float y, float x) { DMF_NOTE_FALLBACK; return dm_atan2f(y, x); }
+RAYN_SLOW float dmf_slow_log(float x) { DMF_NOTE_FALLBACK; return dm_logf(x); }
 
 /* step 2: d is within eps*|d| of the reference double; true + the float when rounding cannot differ */
 RAYN_HD bool dmf_round_safe(double d, double eps, float* out) {
@@ -115,6 +117,41 @@ RAYN_HD double dmf_log_core(double x) {
     double logm = 2.0 * s * p;
     double ef = (double)e;
     return ef * LN2_HI + (ef * LN2_LO + logm);
+}
+
+/* r6: ln of a positive normal float for dmf_logf (the Mandelbulb distance estimator's logarithm, an extension outside the reference) WITHOUT the binary64
+ * division and the 12-term series of dm_log_core: x = 2^e m, interval i = top 7 mantissa bits, r = m inv_i - 1 (one fma, |r| <= 2^-7; intervals >= 53
+ * take m / 2 and e + 1 so that x near 1 has e = 0), ln x = e ln 2 + l_i + log1p(r), log1p through r^7 (rayn_logtab.h, tools/gen_log_table.py).
+ * Error against the true logarithm: the fma's rounding of r (2^-53 absolute = 2^-45 of a 2^-8 r, but ABSOLUTE 2^-53 in the sum), the table's l_i
+ * (2^-54 |l_i|), truncation r^8 / 8 <= 2^-59 |r|, the Horner steps (a few 2^-53 |r|): below 4 x 2^-53 of the result wherever no cancellation occurs - and
+ * the only cancellations are factor-2 ones (e ln 2 against l_i of the opposite sign, at most half of it); the two intervals that touch 1 hold inv = 1,
+ * l = 0: r = m - 1 is exact and ln x = log1p(r) alone, relative error of the series.  dm_log_core itself is within 1e-15 of the true value.
+ * |d - R| <= 3e-15 |d|; EPS_LOG = 1e-13. */
+#define DMF_EPS_LOG 1.0e-13
+RAYN_HD double dmf_log_tab_core(double x) {
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    const uint64_t u = dm_d2u(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    const uint32_t i = (uint32_t)(u >> 45) & 127u;
+    double m = dm_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1, 2) */
+    if (i >= RAYN_LOGTAB_SPLIT) { m = m * 0.5; e += 1; }
+    const double inv = RAYN_LOGTAB[2u * i], l = RAYN_LOGTAB[2u * i + 1u];
+    const double r = __builtin_fma(m, inv, -1.0);
+    double p = 1.0 / 7.0;
+    p = __builtin_fma(p, r, DM_K(-1.0 / 6.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 5.0));
+    p = __builtin_fma(p, r, DM_K(-1.0 / 4.0));
+    p = __builtin_fma(p, r, DM_K(1.0 / 3.0));
+    p = __builtin_fma(p, r, DM_K(-0.5));
+    const double lg = __builtin_fma(r * r, p, r); /* log1p(r) */
+    const double ef = (double)e;
+    return ef * LN2_HI + (ef * LN2_LO + (l + lg));
+}
+RAYN_HD float dmf_logf(float xf) {
+    float out;
+    if (xf > 1.0e-30f && xf < 1.0e30f && dmf_round_safe(dmf_log_tab_core((double)xf), DMF_EPS_LOG, &out)) return out;
+    return dmf_slow_log(xf);
 }
 
 /* x^y for finite x > 0, x != 1, finite y != 0 with |y ln x| < 87: the exponent a = y * ln x carries an absolute error

@@ -1329,13 +1329,14 @@ void oracle_detmath(uint32_t op, const float* a, const float* b, float* out, uin
         case 2: out[i] = dm_cosf(a[i]); break;
         case 3: out[i] = dm_tanf(a[i]); break;
         case 4: out[i] = dm_atan2f(a[i], b[i]); break;
+        case 6: out[i] = dm_logf(a[i]); break; /* the Mandelbulb extension's logarithm */
         default: out[i] = dm_powf(a[i], b[i]); break;
         }
     }
 }
 int oracle_fma_policy() { return RAYN_FMA_POLICY; }
 /* Host check of include/rayn_detmath_fast.h (what the KERNELS evaluate; the oracle itself keeps using rayn_detmath.h): out = the fast
- * wrapper's result for op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b); stats[0] = number of calls that fell back to the
+ * wrapper's result for op 0 exp, 1 sin, 2 cos, 3 tan, 4 atan2(a,b), 5 pow(a,b), 6 log; stats[0] = number of calls that fell back to the
  * reference evaluation, stats[1] = largest |d_fast - d_ref| / |d_ref| between the two binary64 evaluations over the arguments inside
  * the fast domain (must stay well below the EPS the rounding test assumes). */
 void oracle_detmath_fast(uint32_t op, const float* a, const float* b, float* out, uint64_t n, double* stats) {
@@ -1361,6 +1362,7 @@ void oracle_detmath_fast(uint32_t op, const float* a, const float* b, float* out
             }
             break;
         }
+        case 6: out[i] = dmf_logf(x); if (x > 1.0e-30f && x < 1.0e30f) dev(dmf_log_tab_core((double)x), dm_log_core((double)x)); break;
         default: {
             out[i] = dmf_powf(x, y);
             if (x > 1.0e-30f && x < 1.0e30f && x != 1.0f && y != 0.0f && y > -1.0e4f && y < 1.0e4f) {

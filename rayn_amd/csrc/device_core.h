@@ -175,7 +175,7 @@ struct EvalCtr { uint32_t n = 0, it = 0; };
 // Plain IEEE f32 operations in exactly this order (the oracle restates them lane by lane).
 // The logarithm is kept OUT of line: inlined, its twelve binary64 coefficients are hoisted into 24 scalar registers for the
 // whole march kernel, which then sits at the 102-SGPR ceiling and marches MandelBox scenes 4 % slower (k_shadow1, c3).
-__device__ __attribute__((noinline)) static float bulb_logf(float m) { return dm_logf(m); }
+__device__ __attribute__((noinline)) static float bulb_logf(float m) { return dmf_logf(m); } // r6: table + degree-7 log1p + rounding-safety test, dm_logf as the fallback (rayn_detmath_fast.h)
 // The estimator in three pieces - orbit state at the point, ONE orbit step, the distance from the final (|w|^2, dz) - so that the march kernels
 // written for this SDF (march_bulb.h: one loop trip = one orbit STEP) run exactly the operations of the whole-evaluation form below.
 struct BulbOrbit { f3 w; float m, dz; };
@@ -199,6 +199,7 @@ RD void bulb_step(BulbOrbit& o, f3 p) {
 }
 constexpr float BULB_BAILOUT = 256.0f;
 RD float bulb_finish(float m, float dz) { return 0.25f * bulb_logf(m) * sqrt_rn(m) / dz; }
+RD float bulb_finish_inl(float m, float dz) { return 0.25f * dmf_logf(m) * sqrt_rn(m) / dz; } // the same with the logarithm's fast path inline
 template <bool COUNT>
 RD float mandelbulb_dist(f3 p, uint32_t iterations, EvalCtr& evals) {
     BulbOrbit o = bulb_begin(p);

@@ -1829,6 +1829,7 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
         r = (float)bad;
         break;
     }
+    case 14: r = dmf_logf(a[i]); break; // the Mandelbulb estimator's logarithm as the kernels evaluate it
     default: r = a[i] / b[i]; break;
     }
     out[i] = r;

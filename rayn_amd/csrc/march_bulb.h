@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, K == 2 ? 8 : (K == 3 ? 7 : 6)) k_shadow_b
             float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (act[k]) r = jobs[lane + 64u * k];
             if (act[k] && __float_as_uint(r.w) == BJ_RESULT) { // (an orbit still in flight: next round)
-                const float dist = bulb_finish(r.x, r.y);
+                const float dist = bulb_finish_inl(r.x, r.y);
                 if (COUNT) { evals.n++; evals.it += __float_as_uint(r.z); }
                 bool nan = (cnt[k] & BC_NAN) != 0;
                 int res = -1; // -1 keep marching, 0 occluded, 1 visible

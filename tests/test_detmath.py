@@ -14,7 +14,7 @@ def _ulp_diff(a, b):
 
 
 @pytest.mark.parametrize("op,fn,lo,hi", [
-    (0, np.exp, -40.0, 10.0), (1, np.sin, -20.0, 20.0), (2, np.cos, -20.0, 20.0), (3, np.tan, -1.55, 1.55)])
+    (0, np.exp, -40.0, 10.0), (1, np.sin, -20.0, 20.0), (2, np.cos, -20.0, 20.0), (3, np.tan, -1.55, 1.55), (6, np.log, 1.0e-3, 300.0)])
 def test_unary(oracle, op, fn, lo, hi):
     x = np.random.default_rng(op).uniform(lo, hi, 100000).astype(np.float32)
     got = oracle.detmath(op, x)
@@ -42,7 +42,8 @@ def test_special_values(oracle):
 # ---- include/rayn_detmath_fast.h: what the KERNELS evaluate (host build of the same header, through oracle_detmath_fast) ----
 FAST_CASES = [  # op, a range, b range, EPS the header's rounding test assumes
     (0, (-82.0, 87.0), None, 1.0e-12), (1, (-9000.0, 9000.0), None, 2.0e-12), (2, (-8.0, 8.0), None, 2.0e-12), (3, (-1.6, 1.6), None, 4.0e-12),
-    (4, None, None, 1.0e-12), (5, (0.0, 1.0), (0.05, 310.0), 2.0e-12), (5, (0.5, 40.0), (-12.0, 12.0), 2.0e-12)]
+    (4, None, None, 1.0e-12), (5, (0.0, 1.0), (0.05, 310.0), 2.0e-12), (5, (0.5, 40.0), (-12.0, 12.0), 2.0e-12),
+    (6, (0.0, 300.0), None, 1.0e-13), (6, (0.98, 1.02), None, 1.0e-13), (6, "log-uniform", None, 1.0e-13)]  # r6: ln (Mandelbulb extension): |w|^2 up to the bailout, around 1, all magnitudes
 
 
 @pytest.mark.parametrize("op,ra,rb,eps", FAST_CASES)
@@ -55,6 +56,9 @@ def test_fast_functions_return_the_reference_bits(oracle, op, ra, rb, eps):
     if op == 4:
         a = (rng.standard_normal(n) * 10.0 ** rng.uniform(-4, 4, n)).astype(np.float32)
         b = (rng.standard_normal(n) * 10.0 ** rng.uniform(-4, 4, n)).astype(np.float32)
+    elif ra == "log-uniform":
+        a = (10.0 ** rng.uniform(-29.9, 29.9, n)).astype(np.float32)
+        b = np.zeros(n, np.float32)
     else:
         a = rng.uniform(ra[0], ra[1], n).astype(np.float32)
         b = rng.uniform(rb[0], rb[1], n).astype(np.float32) if rb else np.zeros(n, np.float32)
@@ -78,7 +82,7 @@ def test_fast_functions_special_values(oracle):
     sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 3e38, -3e38, 88.5, -87.5, 1e4, -1e4, 1e-30, 1e30, 0.5, 2.0, 300.0], np.float32)
     a, b = [x.ravel().copy() for x in np.meshgrid(sp, sp)]
     st = (C.c_double * 2)()
-    for op in range(6):
+    for op in range(7):
         out = np.zeros_like(a)
         L.oracle_detmath_fast(C.c_uint32(op), fp(a), fp(b), fp(out), C.c_uint64(a.size), st)
         ref = oracle.detmath(op, a, b)

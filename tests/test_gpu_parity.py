@@ -352,7 +352,8 @@ def test_tuning_variants_are_invisible(oracle, monkeypatch):
     tabs = _tables(oracle, p)
     ref, ctr = oracle.render(wd, p, tabs)
     monkeypatch.setenv("RAYN_HIP_ENV_TUNING", "1")  # the library reads its tuning variables only under this opt-in (rayn_hip.h)
-    for env in ({"RAYN_HIP_FAST_PATH": "0"}, {"RAYN_HIP_PREFETCH_SHADOW": "8", "RAYN_HIP_PREFETCH_EXTEND": "60"}, {"RAYN_HIP_FAST_PATH": "0", "RAYN_HIP_REFILL_SHADOW": "1", "RAYN_HIP_WORKERS": "1"}):
+    for env in ({"RAYN_HIP_FAST_PATH": "0"}, {"RAYN_HIP_PREFETCH_SHADOW": "8", "RAYN_HIP_PREFETCH_EXTEND": "60"}, {"RAYN_HIP_FAST_PATH": "0", "RAYN_HIP_REFILL_SHADOW": "1", "RAYN_HIP_WORKERS": "1"},
+                {"RAYN_HIP_SDF_TEMPLATES": "0"}):  # r6: the single-SDF kernels that read the SDF kind from the object instead of their per-kind instantiations
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = rayn_amd.Context(0)
@@ -383,7 +384,7 @@ def test_bulb_march_kernel_variants_are_invisible(oracle, monkeypatch):
         tabs = _tables(oracle, p)
         cases.append((wd, p, tabs, oracle.render(wd, p, tabs)))
     monkeypatch.setenv("RAYN_HIP_ENV_TUNING", "1")
-    envs = ({"RAYN_HIP_BULB_PATH": "0"}, {}, {"RAYN_HIP_BULB_RAYS": "2", "RAYN_HIP_BULB_STEPS": "2"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_ORBIT_MIN": "0"},
+    envs = ({"RAYN_HIP_BULB_PATH": "0"}, {}, {"RAYN_HIP_BULB_PATH": "0", "RAYN_HIP_SDF_TEMPLATES": "0"}, {"RAYN_HIP_BULB_RAYS": "2", "RAYN_HIP_BULB_STEPS": "2"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_ORBIT_MIN": "0"},
             {"RAYN_HIP_BULB_RAYS": "3", "RAYN_HIP_BULB_ORBIT_MIN": "63", "RAYN_HIP_BULB_PREFETCH": "1"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_STEPS": "2", "RAYN_HIP_BULB_PREFETCH": "200"})
     for env in envs:
         for k, v in env.items():
