@@ -62,7 +62,8 @@ def kernel_source_hash():
     stamped with it, so a stale file is detected."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "device_core.h", "kernels.h", "device_scene.h", "rayn_hip.hip", "Makefile", "../../include/rayn_detmath.h"):
+    for f in ("kernels.hip", "device_core.h", "march_bulb.h", "kernels.h", "device_scene.h", "rayn_hip.hip", "Makefile", "../../include/rayn_detmath.h", "../../include/rayn_detmath_fast.h",
+              "../../include/rayn_logtab.h"):
         h.update(open(os.path.join(ROOT, "rayn_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

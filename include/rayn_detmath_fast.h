@@ -128,7 +128,7 @@ RAYN_HD double dmf_log_core(double x) {
  * l = 0: r = m - 1 is exact and ln x = log1p(r) alone, relative error of the series.  dm_log_core itself is within 1e-15 of the true value.
  * |d - R| <= 3e-15 |d|; EPS_LOG = 1e-13. */
 #define DMF_EPS_LOG 1.0e-13
-RAYN_HD double dmf_log_tab_core(double x) {
+RAYN_HD double dmf_log_tab_core_t(double x, const double* __restrict__ tab /* RAYN_LOGTAB or a copy of it (k_shadow_bulb keeps one in LDS) */) {
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
     const uint64_t u = dm_d2u(x);
@@ -136,7 +136,7 @@ RAYN_HD double dmf_log_tab_core(double x) {
     const uint32_t i = (uint32_t)(u >> 45) & 127u;
     double m = dm_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1, 2) */
     if (i >= RAYN_LOGTAB_SPLIT) { m = m * 0.5; e += 1; }
-    const double inv = RAYN_LOGTAB[2u * i], l = RAYN_LOGTAB[2u * i + 1u];
+    const double inv = tab[2u * i], l = tab[2u * i + 1u];
     const double r = __builtin_fma(m, inv, -1.0);
     double p = 1.0 / 7.0;
     p = __builtin_fma(p, r, DM_K(-1.0 / 6.0));
@@ -148,11 +148,13 @@ RAYN_HD double dmf_log_tab_core(double x) {
     const double ef = (double)e;
     return ef * LN2_HI + (ef * LN2_LO + (l + lg));
 }
-RAYN_HD float dmf_logf(float xf) {
+RAYN_HD double dmf_log_tab_core(double x) { return dmf_log_tab_core_t(x, RAYN_LOGTAB); }
+RAYN_HD float dmf_logf_t(float xf, const double* __restrict__ tab) {
     float out;
-    if (xf > 1.0e-30f && xf < 1.0e30f && dmf_round_safe(dmf_log_tab_core((double)xf), DMF_EPS_LOG, &out)) return out;
+    if (xf > 1.0e-30f && xf < 1.0e30f && dmf_round_safe(dmf_log_tab_core_t((double)xf, tab), DMF_EPS_LOG, &out)) return out;
     return dmf_slow_log(xf);
 }
+RAYN_HD float dmf_logf(float xf) { return dmf_logf_t(xf, RAYN_LOGTAB); }
 
 /* x^y for finite x > 0, x != 1, finite y != 0 with |y ln x| < 87: the exponent a = y * ln x carries an absolute error
  * <= |a| * 2e-15 <= 1.8e-13 (= relative error of e^a), plus exp's 3.1e-13.  EPS_POW = 2e-12. */

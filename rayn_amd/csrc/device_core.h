@@ -199,7 +199,7 @@ RD void bulb_step(BulbOrbit& o, f3 p) {
 }
 constexpr float BULB_BAILOUT = 256.0f;
 RD float bulb_finish(float m, float dz) { return 0.25f * bulb_logf(m) * sqrt_rn(m) / dz; }
-RD float bulb_finish_inl(float m, float dz) { return 0.25f * dmf_logf(m) * sqrt_rn(m) / dz; } // the same with the logarithm's fast path inline
+RD float bulb_finish_inl(float m, float dz, const double* __restrict__ logtab) { return 0.25f * dmf_logf_t(m, logtab) * sqrt_rn(m) / dz; } // the same with the logarithm's fast path inline, its table wherever the caller keeps it
 template <bool COUNT>
 RD float mandelbulb_dist(f3 p, uint32_t iterations, EvalCtr& evals) {
     BulbOrbit o = bulb_begin(p);

@@ -38,6 +38,16 @@ __global__ void __launch_bounds__(256, K == 2 ? 8 : (K == 3 ? 7 : 6)) k_shadow_b
                                                       uint32_t ORBIT_MIN, uint32_t REFILL_MIN, unsigned long long* __restrict__ evals_out) {
     __shared__ float4 s_jobs[4][64 * K];
     float4* const jobs = s_jobs[threadIdx.x >> 6];
+#ifndef RAYN_BULB_LOGTAB_GLOBAL
+    // the logarithm's table (128 x { 1 / c_i, ln c_i }, 2 KB) next to the job lists: an epilogue pass waits for one 128-bit table read per ray, and from LDS that is
+    // a tenth of the latency of the read-only global path
+    __shared__ __attribute__((aligned(16))) double s_logtab[256];
+    s_logtab[threadIdx.x] = RAYN_LOGTAB[threadIdx.x];
+    __syncthreads();
+    const double* const logtab = s_logtab;
+#else
+    const double* const logtab = RAYN_LOGTAB;
+#endif
     const DScene& sc = *scp;
     const uint32_t lane = lane_id();
     const uint32_t n_jobs = ctl->job_count, max_vis = sc.max_vis_marches;
@@ -162,7 +172,7 @@ __global__ void __launch_bounds__(256, K == 2 ? 8 : (K == 3 ? 7 : 6)) k_shadow_b
             float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (act[k]) r = jobs[lane + 64u * k];
             if (act[k] && __float_as_uint(r.w) == BJ_RESULT) { // (an orbit still in flight: next round)
-                const float dist = bulb_finish_inl(r.x, r.y);
+                const float dist = bulb_finish_inl(r.x, r.y, logtab);
                 if (COUNT) { evals.n++; evals.it += __float_as_uint(r.z); }
                 bool nan = (cnt[k] & BC_NAN) != 0;
                 int res = -1; // -1 keep marching, 0 occluded, 1 visible
