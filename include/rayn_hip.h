@@ -366,7 +366,8 @@ int64_t rayn_hip_get_trace(const rayn_ctx* ctx, uint32_t* out, uint64_t cap_reco
  *   Ops 6.. check the kernels' exact replacements of IEEE '/' and sqrt against the hardware IEEE
  *   result: 6 Newton-Raphson a/b, 7 IEEE a/b, 8 sqrt(a), 9/10/11 component x/y/z of v/|v| and
  *   12 |v| (a holds n xyz triples), 13 exhaustive sqrt sweep (out[i] = mismatch count over the
- *   65536 float bit patterns starting at bits(a[i])), 14 ln(a) as the Mandelbulb estimator evaluates it (dmf_logf). */
+ *   65536 float bit patterns starting at bits(a[i])), 14 ln(a) as the Mandelbulb estimator evaluates it (dmf_logf),
+ *   15 exhaustive sweep of 1 / sqrt(a) as the kernels evaluate it (rcp_sqrt_rn) against the IEEE sqrt and division (mismatch count over 65536 patterns), 16 that value. */
 int rayn_hip_probe_sdf_dist(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t hitable_index,
                             const float* pts_xyz, float* out, uint32_t n);
 int rayn_hip_probe_extend(rayn_ctx* ctx, const rayn_frame_params* p, uint32_t depth,

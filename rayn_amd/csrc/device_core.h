@@ -64,7 +64,32 @@ RD float sqrt_rn(float x) {
     return __builtin_sqrtf(x);
 }
 RD float mag(f3 a) { return sqrt_rn(mag_sq(a)); }
-RD f3 normalized(f3 a) { float r = 1.0f / mag(a); return f3{a.x * r, a.y * r, a.z * r}; }
+// fl(1 / fl(sqrt(x))) - the reference's `1.0 / v.mag()` (two roundings) - with the reciprocal taken from the SAME v_rsq_f32: y = rsq(x) is within ~2 ulp of
+// 1 / s for s = sqrt_rn(x), one Newton-Raphson step r1 = y + (1 - s y) y brings it within half an ulp (+ 2^-45), and the residual correction
+// r = r1 + (1 - s r1) r1 (fma: the residual is exact) rounds it correctly.  Verified EXHAUSTIVELY on the device against hipcc's IEEE sqrt and '/'
+// over every float of the window (tests/test_gpu_parity.py, probe op 15); outside the window (0, denormals, huge, inf, NaN, negative) the IEEE sequences run.
+// 9 VALU instructions (one transcendental) instead of 5 + 10 (two: v_rsq_f32, v_rcp_f32).
+#ifndef RAYN_RCP_SQRT_IEEE
+RD float rcp_sqrt_rn(float x) {
+    const uint32_t xb = __float_as_uint(x);
+    // (the second test: when the significand of s is all ones, 1 / s lies just above a rounding tie and the correction rounds the wrong way - Markstein's exception.
+    //  That happens for exactly the two largest significands of x in every other binade, 120 floats in all (tools/passes_r06/diag_rcp_sqrt.py); they take the IEEE path.)
+    if (xb - 0x21800000u < 0x3C000000u && (xb & 0x7FFFFEu) != 0x7FFFFEu) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        const float g = x * y;
+        const float h = 0.5f * y;
+        const float d = __builtin_fmaf(-g, g, x);
+        const float s = __builtin_fmaf(d, h, g); // sqrt_rn(x)
+        float r = __builtin_fmaf(__builtin_fmaf(-s, y, 1.0f), y, y);
+        r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+        return r;
+    }
+    return 1.0f / __builtin_sqrtf(x);
+}
+#else
+RD float rcp_sqrt_rn(float x) { return 1.0f / sqrt_rn(x); } // the r5 form (variant builds: tools/variants/README.md)
+#endif
+RD f3 normalized(f3 a) { float r = rcp_sqrt_rn(mag_sq(a)); return f3{a.x * r, a.y * r, a.z * r}; }
 // a / m (three IEEE divisions in the reference) for m = mag(a): m >= |a_i| always (sqrt(fl(x*x + ..)) >= |x|),
 // so min|a_i| >= 2^-60 and m <= 2^60 put every operand and quotient inside the window where the Newton-Raphson
 // steps of an IEEE '/' need neither v_div_scale nor v_div_fixup (see div_nr); the reciprocal is refined once
@@ -189,7 +214,7 @@ RD void bulb_step(BulbOrbit& o, f3 p) {
     const float y = w.y, y2 = y * y, y4 = y2 * y2;
     const float z = w.z, z2 = z * z, z4 = z2 * z2;
     const float k3 = x2 + z2;
-    const float k2 = 1.0f / sqrt_rn(k3 * k3 * k3 * k3 * k3 * k3 * k3);
+    const float k2 = rcp_sqrt_rn(k3 * k3 * k3 * k3 * k3 * k3 * k3); // 1.0f / sqrt(..)
     const float k1 = x4 + y4 + z4 - 6.0f * y2 * z2 - 6.0f * x2 * y2 + 2.0f * z2 * x2;
     const float k4 = x2 - y2 + z2;
     o.w.x = p.x + 64.0f * x * y * z * (x2 - z2) * k4 * (x4 - 6.0f * x2 * z2 + z4) * k1 * k2;

@@ -1830,6 +1830,18 @@ __global__ void k_probe_detmath(uint32_t op, const float* __restrict__ a, const 
         break;
     }
     case 14: r = dmf_logf(a[i]); break; // the Mandelbulb estimator's logarithm as the kernels evaluate it
+    case 15: { // exhaustive sweep: rcp_sqrt_rn against 1 / IEEE sqrt (IEEE '/') over the 65536 bit patterns from bits(a[i]); returns the mismatch count
+        const uint32_t base = __float_as_uint(a[i]);
+        uint32_t bad = 0;
+        for (uint32_t j = 0; j < 65536u; j++) {
+            const float x = __uint_as_float(base + j);
+            const float r0 = rcp_sqrt_rn(x), r1 = 1.0f / __builtin_sqrtf(x);
+            bad += (__float_as_uint(r0) != __float_as_uint(r1)) && !(r0 != r0 && r1 != r1);
+        }
+        r = (float)bad;
+        break;
+    }
+    case 16: r = rcp_sqrt_rn(a[i]); break;
     default: r = a[i] / b[i]; break;
     }
     out[i] = r;

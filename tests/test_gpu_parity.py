@@ -74,6 +74,24 @@ def test_fast_sqrt_is_ieee_exhaustive(gpu_ctx):
         assert bits_equal(got, np.sqrt(x))
 
 
+def test_fast_rcp_sqrt_is_ieee_exhaustive(gpu_ctx):
+    """rcp_sqrt_rn (1 / |v| of normalized(), the Mandelbulb step's 1 / sqrt(k3^7): sqrt and reciprocal from ONE v_rsq_f32 inside [2^-60, 2^60), the IEEE
+    sequences elsewhere) == fl(1 / fl(sqrt(x))) for EVERY non-negative float bit pattern, plus negative / NaN samples."""
+    import ctypes as C
+    from rayn_amd._lib import lib
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    bases = (np.arange(0, 0x7F80_0000 + 65536, 65536, dtype=np.uint64)).astype(np.uint32)
+    out = np.zeros(bases.size, np.float32)
+    dummy = np.zeros(bases.size, np.float32)
+    assert lib().rayn_hip_probe_detmath(gpu_ctx.h, 15, fp(bases.view(np.float32)), fp(dummy), fp(out), bases.size) == 0
+    assert out.sum() == 0, f"{int(out.sum())} mismatching inputs, first block base 0x{int(bases[np.argmax(out > 0)]):08x}"
+    x = np.concatenate([_rand(100000, -1e6, 1e6, 4), np.array([-0.0, np.nan, -np.inf, np.inf, 0.0, 1e-45, 3e38], np.float32)])
+    got = np.zeros_like(x)
+    assert lib().rayn_hip_probe_detmath(gpu_ctx.h, 16, fp(x), fp(x), fp(got), x.size) == 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert bits_equal(got, np.float32(1.0) / np.sqrt(x))
+
+
 def test_fast_normalise_is_ieee(gpu_ctx):
     """v / |v| through div_by_mag (shared refined reciprocal inside the exponent window, IEEE divisions outside) ==
     three IEEE divisions, for ordinary vectors, vectors with zero / tiny / huge components and extreme ratios."""
