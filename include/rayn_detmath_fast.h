@@ -55,13 +55,29 @@ RAYN_SLOW float dmf_slow_atan2(float y, float x) { DMF_NOTE_FALLBACK; return dm_
 RAYN_SLOW float dmf_slow_log(float x) { DMF_NOTE_FALLBACK; return dm_logf(x); }
 
 /* step 2: d is within eps*|d| of the reference double; true + the float when rounding cannot differ */
+/* r6: the test on the BITS of d instead of two more binary64 operations and two conversions.  A binary64 d with a binary32-normal magnitude rounds to
+ * binary32 by its 29 low significand bits; the rounding boundaries (midpoints of consecutive floats) are exactly the doubles whose low 29 bits are
+ * 0x10000000.  |d - reference| <= eps |d| < eps 2^53 ulp(d), so with MARGIN = the power of two >= eps 2^53 the two round alike whenever the low 29
+ * bits of d are at least MARGIN away from 0x10000000 (mod 2^29: a boundary of the neighbouring float is the same pattern).  One conversion and four
+ * integer operations; magnitudes outside [2^-126, 2^127) (zero, denormal or overflowing floats, inf, NaN) take the reference path. */
+#ifdef DMF_ROUND_SAFE_R5 /* the r3-r5 form, kept for variant builds (tools/variants/README.md): (float)(d - eps d) == (float)(d + eps d) */
 RAYN_HD bool dmf_round_safe(double d, double eps, float* out) {
     const double e = d * eps;
     const float lo = (float)(d - e), hi = (float)(d + e);
     *out = lo;
     const float a = lo < 0.0f ? -lo : lo;
-    return lo == hi && a > 1.0e-36f && a < 3.0e38f; /* normal floats only: denormal / overflow results take the reference path */
+    return lo == hi && a > 1.0e-36f && a < 3.0e38f;
 }
+#else
+RAYN_HD bool dmf_round_safe(double d, double eps, float* out) {
+    const uint32_t margin = eps <= 1.13e-13 ? 1024u : eps <= 9.09e-13 ? 8192u : eps <= 1.81e-12 ? 16384u : eps <= 3.63e-12 ? 32768u : eps <= 7.27e-12 ? 65536u : 0x08000000u;
+    const uint64_t u = dm_d2u(d);
+    *out = (float)d;
+    const uint32_t t = ((uint32_t)u + margin - 0x10000000u) & 0x1FFFFFFFu;
+    const uint32_t ex = (uint32_t)(u >> 52) & 0x7FFu;
+    return t >= 2u * margin && ex - 897u < 253u;
+}
+#endif
 
 /* e^a, a double in (-87, 88): same reduction as dm_exp_core, Taylor through r^10 with fma.
  * |r| <= 0.3466: truncation r^11/11! <= 2.2e-13, relative to e^r >= 0.707: 3.1e-13.  EPS_EXP = 1e-12. */
