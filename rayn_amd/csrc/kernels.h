@@ -96,7 +96,7 @@ struct Tuning {
     // march_bulb.h: the shadow-march kernel written for a single-Mandelbulb scene (K rays per lane, rounds of refill / orbits / epilogues)
     bool bulb_path = true;                // use it when the scene's one SDF is a Mandelbulb ...
     bool bulb = false;                    // ... which the host decides per frame (render_device); never set by a caller
-    uint32_t bulb_steps = 1;              // orbit steps per trip of the orbit phase (1 or 2)
+    uint32_t bulb_steps = 2;              // orbit steps per trip of the orbit phase (1 or 2; r6: 2 since rcp_sqrt_rn made a step cheaper than a trip's bookkeeping is worth - 1 / 2 / 3 / 4 steps: 643 / 613 / 641 / 677 ms of k_shadow_bulb per eighth of bulb3, profiles/r06_exp_bulb_tuning.txt)
     uint32_t bulb_rays = 3;               // rays per lane of k_shadow_bulb (2, 3 or 4)
     uint32_t bulb_orbit_min = 24;         // the orbit phase of a round ends when at most this many lanes are still inside an orbit
     uint32_t bulb_prefetch_min = 32;      // free ray slots of a wave before the bulk queue fetch

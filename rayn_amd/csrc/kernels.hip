@@ -1918,7 +1918,11 @@ void launch_shadow_march(hipStream_t s, bool count, const DScene* sc, Nee nee, u
     const dim3 grid = stride_grid(max_jobs, 256, tun.persistent_blocks);
     if (single_sdf >= 0 && tun.fast_path && tun.bulb) {
 #define RAYN_SHADOW_BULB(C, KK, SS) hipLaunchKernelGGL((k_shadow_bulb<C, KK, SS>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.bulb_orbit_min, tun.bulb_prefetch_min, evals + 2)
-        if (count) { if (tun.bulb_rays == 2) RAYN_SHADOW_BULB(true, 2, 1); else if (tun.bulb_rays == 3) RAYN_SHADOW_BULB(true, 3, 1); else RAYN_SHADOW_BULB(true, 4, 1); }
+        if (count) { // the instrumented kernels run the SAME shape as the product ones (their stage-occupancy counters are quoted for it)
+            if (tun.bulb_rays == 2) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(true, 2, 2); else RAYN_SHADOW_BULB(true, 2, 1); }
+            else if (tun.bulb_rays == 3) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(true, 3, 2); else RAYN_SHADOW_BULB(true, 3, 1); }
+            else { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(true, 4, 2); else RAYN_SHADOW_BULB(true, 4, 1); }
+        }
         else if (tun.bulb_rays == 2) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 2, 2); else RAYN_SHADOW_BULB(false, 2, 1); }
         else if (tun.bulb_rays == 3) { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 3, 2); else RAYN_SHADOW_BULB(false, 3, 1); }
         else { if (tun.bulb_steps == 2) RAYN_SHADOW_BULB(false, 4, 2); else RAYN_SHADOW_BULB(false, 4, 1); }

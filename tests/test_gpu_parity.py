@@ -402,8 +402,8 @@ def test_bulb_march_kernel_variants_are_invisible(oracle, monkeypatch):
         tabs = _tables(oracle, p)
         cases.append((wd, p, tabs, oracle.render(wd, p, tabs)))
     monkeypatch.setenv("RAYN_HIP_ENV_TUNING", "1")
-    envs = ({"RAYN_HIP_BULB_PATH": "0"}, {}, {"RAYN_HIP_BULB_PATH": "0", "RAYN_HIP_SDF_TEMPLATES": "0"}, {"RAYN_HIP_BULB_RAYS": "2", "RAYN_HIP_BULB_STEPS": "2"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_ORBIT_MIN": "0"},
-            {"RAYN_HIP_BULB_RAYS": "3", "RAYN_HIP_BULB_ORBIT_MIN": "63", "RAYN_HIP_BULB_PREFETCH": "1"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_STEPS": "2", "RAYN_HIP_BULB_PREFETCH": "200"})
+    envs = ({"RAYN_HIP_BULB_PATH": "0"}, {}, {"RAYN_HIP_BULB_PATH": "0", "RAYN_HIP_SDF_TEMPLATES": "0"}, {"RAYN_HIP_BULB_RAYS": "2", "RAYN_HIP_BULB_STEPS": "2"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_ORBIT_MIN": "0", "RAYN_HIP_BULB_STEPS": "1"},
+            {"RAYN_HIP_BULB_RAYS": "3", "RAYN_HIP_BULB_ORBIT_MIN": "63", "RAYN_HIP_BULB_PREFETCH": "1", "RAYN_HIP_BULB_STEPS": "1"}, {"RAYN_HIP_BULB_RAYS": "2", "RAYN_HIP_BULB_STEPS": "1"}, {"RAYN_HIP_BULB_RAYS": "4", "RAYN_HIP_BULB_STEPS": "2", "RAYN_HIP_BULB_PREFETCH": "200"})
     for env in envs:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
