@@ -77,7 +77,7 @@ def kernel_source_hash():
 #     epilogue 0.25 ln(m) sqrt(m) / dz (5, the logarithm counted as ONE) = 10  ->  at most 8 x 84 + 10 = 682, less when the orbit escapes early
 #   sdfu::Sphere: |p| - r = 7, no iterations
 SDF_FLOPS = {"mandelbox": (33.0, 8.0), "mandelbulb": (84.0, 10.0), "sphere": (0.0, 7.0)}
-SCENE_SDF = {"s0": "sphere", "s1": "mandelbox", "s2": "mandelbox", "s3": "mandelbox", "ship": "mandelbox", "bulb": "mandelbulb", "bulbv": "mandelbulb"}
+SCENE_SDF = {"s0": "sphere", "s1": "mandelbox", "s2": "mandelbox", "s3": "mandelbox", "ship": "mandelbox", "bulb": "mandelbulb", "bulbv": "mandelbulb", "bulbm": "mandelbulb"}
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= f32-input MFMA peak)
 HBM_PEAK_GBS = 8000.0
 
@@ -94,6 +94,11 @@ WORKLOADS = {
     # the MandelBox of src/sdf.rs:104-141), so nothing in rayn corresponds to this line: it measures the HIP path on the restated extension
     "bulb3": ("bulbv", 1920, 1080, 256, 8, "1920x1080, 1024 spp, 8 bounces, power-8 Mandelbulb SDF + homogeneous volume (rho_s 0.25, rho_t 0.035) [BASELINE metric as literally named; "
               "the Mandelbulb is an EXTENSION - the reference's only fractal is a MandelBox, src/sdf.rs:104-141, so no rayn number can correspond]"),
+    # r6: BASELINE configs[3] / configs[4] WITH THE FRACTAL THEY NAME (the Mandelbulb extension; tile digests: tests/golden/config_digests.json bulb4 / bulb5).  Nothing in rayn corresponds:
+    # its only fractal is the MandelBox and its TracedSDF ignores time (src/sdf.rs:25,59,104-141) - "animated" = S3's moving camera + the bulb translating through center_vel
+    "bulb4": ("bulb", 3840, 2160, 256, 12, "3840x2160, 1024 spp, 12 bounces, power-8 Mandelbulb SDF (EXTENSION), volumes off [BASELINE configs[3] as literally named, an 8-GPU config: 8.49 G paths]"),
+    "bulb5": ("bulbm", 7680, 4320, 1024, 16, "7680x4320, 4096 spp, 16 bounces, power-8 Mandelbulb SDF (EXTENSION) translating during the shutter, moving camera with time-sampled motion blur "
+              "[BASELINE configs[4] as literally named, an 8-GPU config: 135.9 G paths]"),
     # the reference's OWN workload, the only thing rayn itself times (src/main.rs:47-82 on src/setup.rs:46-170 as shipped): here the first
     # frame of a fresh context (cold_ms) is the number that corresponds to a rayn run, and the CPU leg renders the WHOLE frame in the GPU's own 16x16 tiles
     "shipped": ("ship", 1280, 720, 2, 3, "1280x720, 8 spp (SAMPLES = 2), 3 bounces, MandelBox SDF + homogeneous volume, frame 1: the reference's shipped default "
