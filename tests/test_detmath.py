@@ -1,9 +1,12 @@
 """include/rayn_detmath.h (host side, through the oracle's probe): within 1 ulp of a double-precision
 reference and identical under both FMA policies (the pinned functions never use mul_add)."""
 import math
+import os
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ulp_diff(a, b):
@@ -87,3 +90,59 @@ def test_fast_functions_special_values(oracle):
         L.oracle_detmath_fast(C.c_uint32(op), fp(a), fp(b), fp(out), C.c_uint64(a.size), st)
         ref = oracle.detmath(op, a, b)
         assert (((out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref)))).all(), op
+
+
+# ---- r6: dmf_round_safe decides on the BITS of the binary64 result - its soundness claim, tested directly ----
+_ROUND_SAFE_SRC = r"""
+#include <cstdint>
+#include <cstring>
+#include "rayn_detmath_fast.h"
+extern "C" void round_safe_batch(const double* d, double eps, uint64_t n, uint8_t* safe, float* out) {
+    for (uint64_t i = 0; i < n; i++) { float o = 0.0f; safe[i] = dmf_round_safe(d[i], eps, &o) ? 1 : 0; out[i] = o; }
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def round_safe_lib(tmp_path_factory):
+    import ctypes as C
+    import subprocess
+    d = tmp_path_factory.mktemp("round_safe")
+    src, so = str(d / "rs.cpp"), str(d / "librs.so")
+    open(src, "w").write(_ROUND_SAFE_SRC)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), src, "-o", so])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("eps", [1.0e-13, 1.0e-12, 2.0e-12, 4.0e-12])
+def test_round_safe_is_sound_and_not_wasteful(round_safe_lib, eps):
+    """If dmf_round_safe says `safe`, EVERY double within eps |d| of d rounds to the same float (checked at both ends of the interval - rounding is monotonic),
+    and the float it returns is that one.  Doubles are drawn uniformly AND packed around the rounding boundaries (midpoints of consecutive floats), where a wrong
+    margin would show; the share of uniformly drawn doubles that is refused stays below 2^-11 (the fallback stays rare)."""
+    import ctypes as C
+    rng = np.random.default_rng(int(eps * 1e15))
+    n = 2_000_000
+    f = (rng.uniform(1.0, 2.0, n) * np.exp2(rng.integers(-100, 100, n).astype(np.float64))).astype(np.float32)
+    f[: n // 8] = np.float32(1.0) + rng.integers(0, 64, n // 8).astype(np.float32) * np.float32(2.0 ** -23)  # binade edges too
+    mid = (f.astype(np.float64) + np.nextafter(f, np.float32(np.inf)).astype(np.float64)) * 0.5              # exact in binary64
+    near = mid * (1.0 + rng.uniform(-3.0, 3.0, n) * eps) * np.where(rng.integers(0, 2, n) == 0, 1.0, -1.0)
+    uni = rng.uniform(1.0, 2.0, n) * np.exp2(rng.integers(-120, 120, n).astype(np.float64)) * np.where(rng.integers(0, 2, n) == 0, 1.0, -1.0)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-300, 1e300, 2.0 ** -127, 2.0 ** 127, 2.0 ** 128, 3.4e38, 1.17e-38, -1.17e-38], np.float64)
+    for d, uniform in ((near, False), (uni, True), (special, False)):
+        d = np.ascontiguousarray(d)
+        safe = np.zeros(d.size, np.uint8)
+        out = np.zeros(d.size, np.float32)
+        round_safe_lib.round_safe_batch(d.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(eps), C.c_uint64(d.size), safe.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)))
+        s = safe.astype(bool)
+        with np.errstate(over="ignore", invalid="ignore"):
+            lo, hi, me = (d * (1.0 - eps)).astype(np.float32), (d * (1.0 + eps)).astype(np.float32), d.astype(np.float32)
+        assert np.array_equal(out[s].view(np.uint32), me[s].view(np.uint32))
+        assert np.array_equal(lo[s].view(np.uint32), hi[s].view(np.uint32)) and np.array_equal(lo[s].view(np.uint32), me[s].view(np.uint32))
+        assert np.isfinite(out[s]).all() and (np.abs(out[s]) >= np.float32(2.0 ** -126)).all()
+        if uniform:
+            inside = (np.abs(d) >= 2.0 ** -126) & (np.abs(d) < 2.0 ** 127)
+            assert 0 < (~s[inside]).mean() < 2.0 ** -11, (~s[inside]).mean()  # 2 MARGIN / 2^29: 2^-18 .. 2^-12 for the four EPS in use
+        elif d is near:
+            assert 0.05 < s.mean() < 0.95  # the sample straddles the margin: both answers occur
+    assert not safe.any()  # (the last batch: zeros, infinities, NaN, denormal and overflowing magnitudes all take the reference path)
