@@ -308,9 +308,13 @@ RD float sdf_scale(const DHitable& h, float t0) { return h.scale_vel != 0.0f ? h
 #define RAYN_FOLD_X4(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX) RAYN_FOLD_ITER(DIV, BOX)
 // SDFK >= 0: the SDF kind is known at compile time (the single-SDF march kernels are instantiated per kind: no per-evaluation branch, and the registers
 // / scalar constants of the other SDFs are not carried through the march loop); -1: the kind is read from the object
+// SDFK == SDFK_MANDELBOX_12S: the MandelBox in the shape the reference ships (12 fold iterations, src/setup.rs:44) with the short division verified for its fold
+// constants (DHitable::fast_div == 2) - iteration count and division form are compile-time facts too: the march loop carries no mode dispatch at all.
+constexpr int SDFK_MANDELBOX_12S = 100;
 template <bool COUNT, int SDFK = -1>
 RD float sdf_dist(const DHitable& h, f3 p, EvalCtr& evals, float scale) {
-    const uint32_t kind = SDFK >= 0 ? (uint32_t)SDFK : h.sdf_kind;
+    constexpr bool BOX12S = SDFK == SDFK_MANDELBOX_12S;
+    const uint32_t kind = BOX12S ? (uint32_t)RAYN_SDF_MANDELBOX : (SDFK >= 0 ? (uint32_t)SDFK : h.sdf_kind);
     if (COUNT) { evals.n++; evals.it += kind == RAYN_SDF_SPHERE ? 0u : h.iterations; } // the Mandelbulb takes its early exits off again (mandelbulb_dist)
     if (kind == RAYN_SDF_MANDELBOX) {
         const f3 offset = p;
@@ -325,7 +329,9 @@ RD float sdf_dist(const DHitable& h, f3 p, EvalCtr& evals, float scale) {
         asm("" : "+v"(mrs_v));
         // NaN-free inputs stay NaN-free here and a NaN point yields NaN through '-p', so the hardware
         // med3/max (IEEE maxNum) forms are bit-identical to the reference's SSE max/min semantics.
-        if (h.fast_div == 2) {
+        if (BOX12S) {
+            RAYN_FOLD_X4(div_short, RAYN_BOX_FMA) RAYN_FOLD_X4(div_short, RAYN_BOX_FMA) RAYN_FOLD_X4(div_short, RAYN_BOX_FMA)
+        } else if (h.fast_div == 2) {
             uint32_t i = 0;
             if (h.iterations == 12) { // the shipped iteration count (src/setup.rs:44), fully unrolled: 2 % over the rolled loop
                 RAYN_FOLD_X4(div_short, RAYN_BOX_FMA) RAYN_FOLD_X4(div_short, RAYN_BOX_FMA) RAYN_FOLD_X4(div_short, RAYN_BOX_FMA)

@@ -92,6 +92,7 @@ struct Tuning {
     uint32_t prefetch_min_shadow = 32;
     bool fast_path = true;                // single-SDF specialisations k_extend1 / k_shadow1
     bool sdf_templates = true;            // per-SDF-kind instantiations of k_extend1 / k_shadow1 (off: the generic ones that read the kind from the object)
+    bool box12s = true;                   // r6: the instantiation for the MandelBox in its shipped shape (12 iterations + verified short division known at compile time; RAYN_HIP_BOX12S=0 keeps the per-kind one)
     int sdf_kind = -1;                    // RAYN_SDF_* of the scene's single TracedSDF (-1: none / several), set per frame by the host: picks the instantiation
     // march_bulb.h: the shadow-march kernel written for a single-Mandelbulb scene (K rays per lane, rounds of refill / orbits / epilogues)
     bool bulb_path = true;                // use it when the scene's one SDF is a Mandelbulb ...

@@ -1886,6 +1886,7 @@ void launch_extend(hipStream_t s, bool count, const DScene* sc, uint32_t depth, 
         // one instantiation per SDF kind of the scene's single TracedSDF (Tuning::sdf_kind, set per frame by the host); the counting variants stay generic
 #define RAYN_EXTEND1(C, KIND) hipLaunchKernelGGL((k_extend1<C, KIND>), grid, dim3(256), 0, s, sc, depth, (uint32_t)single_sdf, q, ctl, pool, ent_obj, tun.prefetch_min_extend, evals)
         if (count) RAYN_EXTEND1(true, -1);
+        else if (tun.sdf_kind == SDFK_MANDELBOX_12S) RAYN_EXTEND1(false, SDFK_MANDELBOX_12S);
         else if (tun.sdf_kind == RAYN_SDF_MANDELBOX) RAYN_EXTEND1(false, RAYN_SDF_MANDELBOX);
         else if (tun.sdf_kind == RAYN_SDF_MANDELBULB) RAYN_EXTEND1(false, RAYN_SDF_MANDELBULB);
         else RAYN_EXTEND1(false, -1);
@@ -1930,6 +1931,7 @@ void launch_shadow_march(hipStream_t s, bool count, const DScene* sc, Nee nee, u
     } else if (single_sdf >= 0 && tun.fast_path) {
 #define RAYN_SHADOW1(C, KIND) hipLaunchKernelGGL((k_shadow1<C, KIND>), grid, dim3(256), 0, s, sc, (uint32_t)single_sdf, nee, ctl, tun.prefetch_min_shadow, evals + 2)
         if (count) RAYN_SHADOW1(true, -1);
+        else if (tun.sdf_kind == SDFK_MANDELBOX_12S) RAYN_SHADOW1(false, SDFK_MANDELBOX_12S);
         else if (tun.sdf_kind == RAYN_SDF_MANDELBOX) RAYN_SHADOW1(false, RAYN_SDF_MANDELBOX);
         else RAYN_SHADOW1(false, -1); // (sphere SDF; a Mandelbulb scene with the k_shadow_bulb path switched off)
 #undef RAYN_SHADOW1

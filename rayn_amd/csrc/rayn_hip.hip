@@ -255,6 +255,8 @@ int scene_march_kernels(const rayn_ctx* ctx, const DScene& hs, const rayn_frame_
     if (hs.n_sdf == 1) for (uint32_t i = 0; i < hs.n_hitables; i++) if (hs.h[i].kind == RAYN_HITABLE_TRACED_SDF) single_sdf = (int)i;
     *tun = ctx->tun;
     tun->sdf_kind = single_sdf >= 0 && ctx->tun.sdf_templates ? (int)hs.h[single_sdf].sdf_kind : -1;
+    // the MandelBox in the reference's shipped shape (12 iterations, short division verified for its constants): the instantiation that knows both at compile time
+    if (tun->sdf_kind == (int)RAYN_SDF_MANDELBOX && ctx->tun.box12s && hs.h[single_sdf].fast_div == 2u && hs.h[single_sdf].iterations == 12u) tun->sdf_kind = 100; // SDFK_MANDELBOX_12S (device_core.h)
     tun->bulb = ctx->tun.bulb_path && single_sdf >= 0 && hs.h[single_sdf].sdf_kind == RAYN_SDF_MANDELBULB && hs.h[single_sdf].iterations >= 1 &&
                 p.max_marches < 0xFFFFu && p.max_vis_marches < 0xFFFFu;
     return single_sdf;
@@ -940,6 +942,7 @@ int rayn_hip_create(int device, rayn_ctx** out) {
         if (const char* e = getenv("RAYN_HIP_BULB_PATH")) ctx->tun.bulb_path = atoi(e) != 0;
         if (const char* e = getenv("RAYN_HIP_BULB_STEPS")) ctx->tun.bulb_steps = atoi(e) == 2 ? 2u : 1u;
         if (const char* e = getenv("RAYN_HIP_BULB_ORBIT_MIN")) ctx->tun.bulb_orbit_min = (uint32_t)std::max(0, atoi(e));
+        if (const char* e = getenv("RAYN_HIP_BOX12S")) ctx->tun.box12s = atoi(e) != 0;
         if (const char* e = getenv("RAYN_HIP_BULB_RAYS")) ctx->tun.bulb_rays = (uint32_t)std::min(4, std::max(2, atoi(e)));
         if (const char* e = getenv("RAYN_HIP_BULB_PREFETCH")) ctx->tun.bulb_prefetch_min = (uint32_t)std::max(1, atoi(e));
     }

@@ -371,7 +371,7 @@ def test_tuning_variants_are_invisible(oracle, monkeypatch):
     ref, ctr = oracle.render(wd, p, tabs)
     monkeypatch.setenv("RAYN_HIP_ENV_TUNING", "1")  # the library reads its tuning variables only under this opt-in (rayn_hip.h)
     for env in ({"RAYN_HIP_FAST_PATH": "0"}, {"RAYN_HIP_PREFETCH_SHADOW": "8", "RAYN_HIP_PREFETCH_EXTEND": "60"}, {"RAYN_HIP_FAST_PATH": "0", "RAYN_HIP_REFILL_SHADOW": "1", "RAYN_HIP_WORKERS": "1"},
-                {"RAYN_HIP_SDF_TEMPLATES": "0"}):  # r6: the single-SDF kernels that read the SDF kind from the object instead of their per-kind instantiations
+                {"RAYN_HIP_SDF_TEMPLATES": "0"}, {"RAYN_HIP_BOX12S": "0"}):  # r6: the single-SDF kernels that read the SDF kind from the object instead of their per-kind instantiations
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = rayn_amd.Context(0)
