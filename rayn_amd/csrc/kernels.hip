@@ -247,6 +247,7 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
     uint32_t c_P = 0, c_ent = 0, c_ids = 0, m = 0;
     EvalCtr evals;
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0};
+    f3 pt = f3{0, 0, 0}; // the current ray's next march point (unused under -DRAYN_MARCH_POINT_SELECT)
     float c_pre = 0.0f, c_post = 0.0f, t = 0.0f;
     float c_scale = h.scale, n_scale = h.scale; // MandelBox scale at the packet time (extension; h.scale itself in the reference's case)
     // prefetched next ray
@@ -309,13 +310,20 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
             c_has = true; n_has = false;
             o = n_o; d = n_d; c_pre = n_pre; c_post = n_post; c_ids = n_ids; c_P = n_P; c_ent = n_ent; c_scale = n_scale;
             first = true;
+#ifndef RAYN_MARCH_POINT_SELECT
+            pt = n_o; // the first evaluation is at the origin
+#endif
         }
         if (__ballot(c_has) == 0) {
             if (exhausted) break;
             continue;
         }
         if (c_has) { // TracedSDF::hit, src/sdf.rs:59-83, one evaluation per loop trip
+#ifdef RAYN_MARCH_POINT_SELECT
             const f3 p = first ? o : muladd3(d, t, o);
+#else
+            const f3 p = pt; // r6: the march point is STATE - set at promotion (the origin) and at the end of a trip that goes on - instead of a per-trip select between the origin and o + d t
+#endif
             const float dist = sdf_dist<COUNT, SDFK>(h, p, evals, c_scale);
             bool done;
             if (first) { t = dist; nan = dist != dist; first = false; m = 0; done = max_marches == 0; }
@@ -336,6 +344,9 @@ __global__ void __launch_bounds__(256) k_extend1(const DScene* __restrict__ scp,
                 ent_obj[c_ent] = (uint8_t)id;
                 c_has = false;
             }
+#ifndef RAYN_MARCH_POINT_SELECT
+            else pt = muladd3(d, t, o); // the next trip's point (Ray::point_at: the same operations the select form ran at the top of that trip)
+#endif
         }
     }
     if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
@@ -1068,6 +1079,7 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
     uint32_t ref = 0, n_ref = 0, m = 0;
     EvalCtr evals;
     f3 start = f3{0, 0, 0}, dir = f3{0, 0, 0}, n_start = f3{0, 0, 0}, n_dir = f3{0, 0, 0};
+    f3 pt = f3{0, 0, 0}; // the current segment's next march point (unused under -DRAYN_MARCH_POINT_SELECT)
     float max_dist = 0.0f, n_max = 0.0f, t = 0.0f;
     float c_scale = h.scale, n_scale = h.scale; // MandelBox scale at the packet time (extension)
     for (;;) {
@@ -1109,13 +1121,20 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
             c_has = true; n_has = false;
             start = n_start; dir = n_dir; max_dist = n_max; ref = n_ref; c_scale = n_scale;
             first = true;
+#ifndef RAYN_MARCH_POINT_SELECT
+            pt = n_start; // the first evaluation is at the segment start
+#endif
         }
         if (__ballot(c_has) == 0) {
             if (exhausted) break;
             continue;
         }
         if (c_has) { // TracedSDF::occluded, src/sdf.rs:25-57
+#ifdef RAYN_MARCH_POINT_SELECT
             const f3 p = first ? start : muladd3(dir, t, start);
+#else
+            const f3 p = pt; // (see k_extend1)
+#endif
             const float dist = sdf_dist<COUNT, SDFK>(h, p, evals, c_scale);
             int res = -1; // -1 keep marching, 0 occluded, 1 visible
             if (first) {
@@ -1130,6 +1149,9 @@ __global__ void __launch_bounds__(256) k_shadow1(const DScene* __restrict__ scp,
                 }
             }
             if (res >= 0) { if (res == 1) nee.vis[ref] = 1; c_has = false; } // only VISIBLE results are written (see Nee::vis)
+#ifndef RAYN_MARCH_POINT_SELECT
+            else pt = muladd3(dir, t, start);
+#endif
         }
     }
     if (COUNT && evals.n) { atomicAdd(evals_out, (unsigned long long)evals.n); atomicAdd(evals_out + 4, (unsigned long long)evals.it); }
